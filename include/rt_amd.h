@@ -1,0 +1,202 @@
+/*
+ * rt_amd.h — C ABI of the MI355X render-loop library (libraytracer_amd.so).
+ *
+ * The reference (RichardXiao13/Raytracer) has no plugin/FFI interface; its seam is the
+ * C++ call `PNG *Scene::render(int numThreads, int seed)` (src/scene/raytracer.h:50,
+ * src/scene/raytracer.cpp:287-300) and, below it, `Scene::findClosestObject`
+ * (src/scene/raytracer.h:51, src/scene/raytracer.cpp:187-196). This header is what a
+ * binding for that seam binds: the host flattens its scene graph into the plain
+ * arrays of RtSceneDesc, hands them over once (rt_scene_create uploads them to HBM),
+ * and then calls rt_render / rt_trace_* any number of times.
+ *
+ * Conventions: plain pointers and sizes, opaque handles, int status codes
+ * (0 = RT_OK), no exceptions cross the boundary, the caller owns every host buffer
+ * it passes in. Errors: the failing call returns non-zero (or NULL) and
+ * rt_last_error() returns a thread-local message.
+ *
+ * The CPU restatement used by the tests (oracle/rt_oracle.cpp) implements the same
+ * entry points with an `rto_` prefix over the same structs.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_ERR_INVALID 1   /* bad argument / unsupported scene (message says which) */
+#define RT_ERR_DEVICE 2    /* HIP runtime error */
+#define RT_ERR_NOMEM 3
+
+/* ---- scene description (host arrays; copied during rt_scene_create) ---------------- */
+
+/* One flattened BVH node, byte-for-byte the reference's BVH::FlattenedNode
+ * (src/acceleration/BVH.h:49-61): pre-order DFS array, left child = index + 1,
+ * right child = rightOrStart; leaf iff numObjects > 0, then rightOrStart is the
+ * first object index (src/acceleration/BVH.cpp:411-428). */
+typedef struct RtBvhNode {
+  float aabbMin[3];
+  float aabbMax[3];
+  int32_t rightOrStart;
+  int32_t numObjects;
+} RtBvhNode;
+
+enum { RT_PRIM_TRIANGLE = 0, RT_PRIM_SPHERE = 1 };
+
+/* MaterialType order of src/scene/Material.h:8-14. RT_MAT_DEFAULT is the
+ * default-constructed material (one Lambertian lobe, src/scene/Material.cpp:4-11). */
+enum { RT_MAT_DEFAULT = 0, RT_MAT_GLASS = 1, RT_MAT_MIRROR = 2, RT_MAT_PLASTIC = 3, RT_MAT_METAL = 4 };
+
+typedef struct RtMaterial { /* src/scene/Material.h:41-55 */
+  int32_t type;
+  float Kd, Ks, eta, Kr, Kt, Ka, roughness;
+} RtMaterial;
+
+typedef struct RtPlane { /* src/scene/Object.h:123-143; not part of the BVH */
+  float normal[3];     /* normalised, possibly flipped toward the camera by the parser */
+  float point[3];
+  float texTopLeft[3];
+  float texZoom;
+  float texShift[3];
+  float color[4];
+  int32_t material;
+  int32_t texture;     /* index into textures, -1 = none */
+} RtPlane;
+
+enum { RT_LIGHT_DISTANT = 0, RT_LIGHT_POINT = 1, RT_LIGHT_ENVIRONMENT = 2 };
+
+typedef struct RtLight { /* src/scene/Object.h:54-105 */
+  int32_t type;
+  float color[4];
+  float v[3];          /* distant: direction; point: center; environment: center */
+  float radius;        /* environment only */
+  int32_t texture;     /* environment luminance map, -1 = constant colour */
+} RtLight;
+
+typedef struct RtTexture { /* linear float RGBA, row-major, what PNG::readFromFile leaves in image_ (src/image/PNG.cpp:125-147) */
+  int32_t width, height;
+  const float *rgba;
+} RtTexture;
+
+typedef struct RtCamera { /* src/scene/Camera.h:18-21 */
+  float eye[3], forward[3], right[3], up[3];
+} RtCamera;
+
+typedef struct RtOptions { /* Scene width_/height_ + SceneOptions, src/scene/raytracer.h:34-42 */
+  int32_t width, height;
+  float bias, exposure;
+  int32_t maxBounces, numRays;
+  int32_t fisheye;
+  float focus, lens;
+} RtOptions;
+
+typedef struct RtSceneDesc {
+  /* BVH over `prims`, exactly as BVH::BVH leaves it (src/acceleration/BVH.cpp:161-182). */
+  const RtBvhNode *nodes;
+  int32_t numNodes;
+  /* Scene::objects in BVH (post-build) order. */
+  int32_t numPrims;
+  const int32_t *primKind;      /* [numPrims] RT_PRIM_* */
+  const float *primHit;         /* [numPrims*12] triangle: p1, normal, e1, e2 (src/scene/Object.h:162-165);
+                                   sphere: center, r, then 8 unused floats */
+  const float *primNormals;     /* [numPrims*9] triangle n1,n2,n3 (unused for spheres) */
+  const float *primTexCoords;   /* [numPrims*9] triangle t1,t2,t3; may be NULL when no triangle is textured */
+  const float *primColor;       /* [numPrims*4] Object::color */
+  const int32_t *primMaterial;  /* [numPrims] index into materials */
+  const int32_t *primTexture;   /* [numPrims] index into textures, -1 = none */
+  const int32_t *primOrigIndex; /* [numPrims] insertion index before the BVH reordered objects; reported as hit id */
+  int32_t numPlanes;
+  const RtPlane *planes;
+  int32_t numMaterials;
+  const RtMaterial *materials;
+  int32_t numLights;
+  const RtLight *lights;
+  int32_t numTextures;
+  const RtTexture *textures;
+  RtCamera camera;
+  RtOptions options;
+} RtSceneDesc;
+
+/* ---- rendering ---------------------------------------------------------------------- */
+
+enum {
+  RT_RNG_COUNTER = 0,     /* per-(pixel,sample) counter-based stream: independent of partition / GPU count */
+  RT_RNG_REF_MT19937 = 1  /* oracle only: one std::mt19937 consumed in the reference's -t1 order */
+};
+
+typedef struct RtRenderParams {
+  int32_t rngMode;        /* RT_RNG_* (the HIP library only accepts RT_RNG_COUNTER) */
+  uint32_t seed;
+  /* image-tile partition: tiles of tileW x tileH pixels, row-major tile index i is rendered
+   * iff i % partCount == partIndex. partCount <= 1 renders the whole image. */
+  int32_t partIndex, partCount;
+  int32_t tileW, tileH;
+  int32_t samplesPerPass; /* camera samples per pixel traced per wavefront pass; 0 = library default */
+  int32_t collectCounters;/* non-zero: count traversal work (inner expansions, primitive tests); slower */
+  int32_t skipExposure;   /* non-zero: leave out Scene::expose (src/scene/raytracer.cpp:303-312) */
+} RtRenderParams;
+
+typedef struct RtStats {
+  uint64_t cameraSamples;
+  uint64_t raysClosest;    /* Scene::findClosestObject-equivalent queries from the path loop + point lights */
+  uint64_t raysAny;        /* Scene::findAnyObject-equivalent queries (distant / environment lights) */
+  uint64_t innerExpansions;/* only with collectCounters */
+  uint64_t primTests;      /* only with collectCounters */
+  uint64_t planeTests;
+  double msTotal;          /* render phase, device-side (HIP events on the library's stream) */
+  double msRaygen, msExtend, msShade, msShadow, msDirect, msAccumulate, msResolve;
+  uint32_t launchesExtend, launchesShadow;
+  uint32_t passes;
+} RtStats;
+
+typedef struct RtScene RtScene;
+
+/* Selects `device` (hipSetDevice), builds device copies of the scene. Returns NULL on error.
+ * Replaces: the scene state Scene::render reads (src/scene/raytracer.cpp:287-300) — objects,
+ * planes, lights, camera, options and the BVH built at :288. */
+RtScene *rt_scene_create(const RtSceneDesc *desc, int device);
+void rt_scene_destroy(RtScene *scene);
+
+/* Changes options that do not alter geometry (numRays, maxBounces, bias, exposure, fisheye, focus, lens,
+ * width, height) and the camera, without re-uploading the scene. */
+int rt_scene_set_view(RtScene *scene, const RtCamera *camera, const RtOptions *options);
+
+/* Primary-ray closest hits for the pixel rectangle [x0,x0+w) x [y0,y0+h), un-jittered pixel centres
+ * (the numRays == 1 form of src/scene/raytracer.cpp:44-47 followed by Scene::findClosestObject, :187-196).
+ * primId[j] = original insertion index of the hit object, numPrims + k for plane k, -1 for a miss;
+ * t[j] = IntersectionInfo::t (+inf on a miss). Row-major over the rectangle; host buffers. */
+int rt_trace_primary(RtScene *scene, int32_t x0, int32_t y0, int32_t w, int32_t h, int32_t *primId, float *t);
+
+/* Scene::findClosestObject (src/scene/raytracer.cpp:187-196) for n arbitrary rays.
+ * origins/directions: [n*3] host floats, directions un-normalised as the reference passes them.
+ * Outputs (host, any may be NULL): primId[n], t[n], point[n*3], normal[n*3]. */
+int rt_trace_closest(RtScene *scene, int64_t n, const float *origins, const float *directions,
+                     int32_t *primId, float *t, float *point, float *normal);
+
+/* Scene::findAnyObject != nullptr (src/scene/raytracer.cpp:174-185) for n rays; occluded[n] = 0/1. */
+int rt_trace_any(RtScene *scene, int64_t n, const float *origins, const float *directions, uint8_t *occluded);
+
+/* The whole of Scene::render's pixel loop (src/scene/raytracer.cpp:253-285 with the worker chosen at :290-299):
+ * writes the clipped (and, unless skipExposure, exposed) linear float RGBA framebuffer, row-major
+ * width*height*4 floats, i.e. the contents of the PNG object Scene::render returns. Pixels outside this
+ * call's tile partition are written as 0. rgbaOut may be NULL (result stays on the device, see
+ * rt_framebuffer_device). stats may be NULL. */
+int rt_render(RtScene *scene, const RtRenderParams *params, float *rgbaOut, RtStats *stats);
+
+/* Device pointer of the float RGBA framebuffer of the last rt_render on this scene (width*height*4 floats). */
+const float *rt_framebuffer_device(RtScene *scene);
+
+/* PNG::saveToFile's pixel conversion (src/image/PNG.cpp:149-157): sRGB transfer + round(c*255), on the
+ * device, from the framebuffer of the last rt_render; rgba8Out: width*height*4 bytes (host). */
+int rt_resolve_rgba8(RtScene *scene, uint8_t *rgba8Out);
+
+const char *rt_last_error(void);
+const char *rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

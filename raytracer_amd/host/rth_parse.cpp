@@ -1,0 +1,536 @@
+// Scene front-ends: the keyword-per-line .txt format (src/parser/parser.cpp:144-360), the tag-tree
+// .sdml format (src/parser/ParserTree.cpp) and the Wavefront OBJ loader (src/parser/parser.cpp:47-142).
+// They run once per render on the host; what matters is that they produce the same floats, the same
+// object order and the same quirks (normal flips toward the camera, lights parsed last, OBJ recentring).
+#include <fstream>
+#include <functional>
+#include <sstream>
+#include <stdexcept>
+#include <unordered_map>
+
+#include "rth_scene.h"
+
+namespace rth {
+namespace {
+
+constexpr float kInf = std::numeric_limits<float>::infinity();
+
+// parser.cpp:16-31 — empty items are dropped
+std::vector<std::string> split(const std::string &s, char delim) {
+  std::vector<std::string> elems;
+  std::istringstream iss(s);
+  std::string item;
+  while (std::getline(iss, item, delim))
+    if (!item.empty()) elems.push_back(item);
+  return elems;
+}
+
+bool endsWith(const std::string &value, const std::string &ending) {
+  return ending.size() <= value.size() && std::equal(ending.rbegin(), ending.rend(), value.rbegin());
+}
+
+// parser.cpp:33-45 — "a/b/c", "a//c" (missing fields become -1)
+std::vector<int> parseOBJPoint(const std::string &s) {
+  std::vector<int> indices;
+  std::istringstream iss(s);
+  std::string item;
+  while (std::getline(iss, item, '/')) indices.push_back(item.empty() ? -1 : std::stoi(item));
+  return indices;
+}
+
+std::string trimCopy(std::string s) {
+  auto notSpace = [](unsigned char ch) { return !std::isspace(ch); };
+  s.erase(std::find_if(s.rbegin(), s.rend(), notSpace).base(), s.end());
+  s.erase(s.begin(), std::find_if(s.begin(), s.end(), notSpace));
+  return s;
+}
+
+// The named presets of src/scene/Material.h:57-64, created on first use per scene.
+struct MaterialBook {
+  Scene &scene;
+  std::unordered_map<std::string, int> named;
+  explicit MaterialBook(Scene &s) : scene(s) {}
+  int get(const std::string &name) {
+    auto it = named.find(name);
+    if (it != named.end()) return it->second;
+    int id;
+    if (name == "glass") id = scene.addMaterial(0.0f, 1.0f, 1.5f, 1.0f, 1.0f, 0.0f, 0.0f, RT_MAT_GLASS);
+    else if (name == "plastic") id = scene.addMaterial(0.5f, 0.5f, 1.3f, 1.0f, 0.0f, 0.0f, 0.1f, RT_MAT_PLASTIC);
+    else if (name == "copper") id = scene.addMaterial(0.0f, 1.0f, 0.23883f, 0.9553f, 0.0f, 3.415658f, 0.01f, RT_MAT_METAL);
+    else if (name == "gold") id = scene.addMaterial(0.0f, 1.0f, 0.18104f, 0.99f, 0.0f, 3.068099f, 0.01f, RT_MAT_METAL);
+    else if (name == "mirror") id = scene.addMaterial(0.0f, 1.0f, 0.0f, 0.9f, 0.0f, 0.0f, 0.0f, RT_MAT_MIRROR);
+    else id = scene.addMaterialDefault();
+    named[name] = id;
+    return id;
+  }
+};
+
+// src/scene/Material.h:67-74
+const std::unordered_map<std::string, Color> &materialColors() {
+  static const std::unordered_map<std::string, Color> m = {
+      {"copper", Color(0.4793201831f, 0.1714411007f, 0.03310476657f)},
+      {"pale copper", Color(0.7011018919f, 0.2541520943f, 0.1356333297f)},
+      {"copper red", Color(0.5972017884f, 0.152926152f, 0.08228270713f)},
+      {"copper penny", Color(0.4178850708f, 0.1589608351f, 0.1412632911f)},
+      {"gold", Color(1.0f, 0.6795424696330938f, 0.0f)},
+      {"metallic gold", Color(0.6583748172794485f, 0.4286904966139066f, 0.0382043715953465f)}};
+  return m;
+}
+
+int materialTypeByName(const std::string &s) {  // src/scene/Material.h:16-22
+  if (s == "dialectric") return RT_MAT_DEFAULT;
+  if (s == "glass") return RT_MAT_GLASS;
+  if (s == "mirror") return RT_MAT_MIRROR;
+  if (s == "plastic") return RT_MAT_PLASTIC;
+  if (s == "metal") return RT_MAT_METAL;
+  throw std::out_of_range("unknown material type '" + s + "'");
+}
+
+// Orient a triangle's normal against the camera when it is in front of it and faces along forward
+// (parser.cpp:250-257, ParserTree.cpp:438-445), then use it as all three shading normals.
+void orientTriangle(Prim &t, const Camera &camera) {
+  if (dot(camera.forward, t.centroid - camera.eye) > 0 && dot(camera.forward, t.normal) > 0) t.normal = -t.normal;
+  t.n1 = t.normal; t.n2 = t.normal; t.n3 = t.normal;
+}
+
+// ------------------------------------------------------------------ .txt
+std::unique_ptr<Scene> readTxt(std::istream &in, std::string &error) {
+  std::string line;
+  std::getline(in, line);
+  std::vector<std::string> info = split(line, ' ');
+  if (info.size() != 4) {
+    error = "Supplied PNG info doesn't have the correct number of arguments. Expected 4. Got " +
+            std::to_string(info.size()) + ".";
+    return nullptr;
+  }
+  if (info[0] != "png") { error = "Expected PNG image type. Got " + info[0] + "."; return nullptr; }
+  auto scene = std::make_unique<Scene>();
+  scene->width = std::stoi(info.at(1));
+  scene->height = std::stoi(info.at(2));
+  scene->filename = info.at(3);
+  std::vector<Vec3> points;
+  int currentMaterial = scene->addMaterialDefault();
+  Color currentColor(1, 1, 1, 1);
+  int currentTexture = -1;
+  Camera camera;
+  Options options;
+  auto f = [&](size_t i) { return std::stof(info.at(i)); };
+
+  while (std::getline(in, line)) {
+    info = split(line, ' ');
+    if (info.empty()) continue;
+    const std::string keyword = info.at(0);
+    if (keyword == "sphere") {
+      scene->addPrim(makeSphere(Vec3(f(1), f(2), f(3)), f(4), currentColor, currentMaterial, currentTexture));
+    } else if (keyword == "sun") {
+      Light l; l.type = RT_LIGHT_DISTANT; l.v = Vec3(f(1), f(2), f(3)); l.color = currentColor;
+      scene->lights.push_back(l);
+    } else if (keyword == "color") {
+      currentColor = Color(f(1), f(2), f(3), 1);
+    } else if (keyword == "plane") {
+      float A = f(1), B = f(2), C = f(3), D = f(4);
+      scene->planes.push_back(makePlane(Vec3(A, B, C), D, currentColor, currentMaterial));
+    } else if (keyword == "bulb") {
+      Light l; l.type = RT_LIGHT_POINT; l.v = Vec3(f(1), f(2), f(3)); l.color = currentColor;
+      scene->lights.push_back(l);
+    } else if (keyword == "environment") {
+      Light l; l.type = RT_LIGHT_ENVIRONMENT; l.radius = f(1); l.v = scene->worldCenter();
+      if (info.size() < 3) {
+        l.color = currentColor;
+      } else {
+        (void)f(2);  // scale: parsed, stored, never read by the render loop
+        l.color = Color();
+        l.texture = scene->loadTexture(info.at(3));
+      }
+      scene->lights.push_back(l);
+    } else if (keyword == "xyz") {
+      points.emplace_back(f(1), f(2), f(3));
+    } else if (keyword == "trif") {
+      int idx[3];
+      for (int k = 0; k < 3; ++k) {
+        idx[k] = std::stoi(info.at(k + 1)) - 1;
+        if (idx[k] < 0) idx[k] += (int)points.size() + 1;
+      }
+      Prim t = makeTriangle(points.at(idx[0]), points.at(idx[1]), points.at(idx[2]), currentColor, currentMaterial);
+      orientTriangle(t, camera);
+      scene->addPrim(t);
+    } else if (keyword == "expose") {
+      options.exposure = f(1);
+    } else if (keyword == "bounces") {
+      options.maxBounces = std::stoi(info.at(1));
+    } else if (keyword == "aa") {
+      options.numRays = std::stoi(info.at(1));
+    } else if (keyword == "roughness" || keyword == "ior") {
+      // These mutate fields of a material whose lobes were already built from the constructor
+      // arguments (parser.cpp:268-270, 288-290); the render loop never reads the fields again.
+      (void)f(1);
+    } else if (keyword == "eye") {
+      camera.eye = Vec3(f(1), f(2), f(3));
+    } else if (keyword == "forward") {
+      camera.setForward(Vec3(f(1), f(2), f(3)));
+    } else if (keyword == "up") {
+      camera.setUp(Vec3(f(1), f(2), f(3)));
+    } else if (keyword == "fisheye") {
+      options.fisheye = true;
+    } else if (keyword == "dof") {
+      options.focus = f(1);
+      options.lens = f(2);
+    } else if (keyword == "glass") {
+      currentColor = Color(0, 0, 0, 0);
+      currentMaterial = scene->addMaterial(0.0f, 1.0f, 1.5f, 1.0f, 1.0f, 0.0f, 0.0f, RT_MAT_GLASS);
+    } else if (keyword == "plastic") {
+      currentMaterial = scene->addMaterial(0.5f, 0.5f, 1.3f, 1.0f, 0.0f, 0.0f, 0.1f, RT_MAT_PLASTIC);
+    } else if (keyword == "none") {
+      currentTexture = -1;
+      currentMaterial = scene->addMaterialDefault();
+    } else if (keyword == "copper") {
+      currentColor = Color(0.7011018919f, 0.2541520943f, 0.1356333297f);
+      currentMaterial = scene->addMaterial(0.0f, 1.0f, 0.23883f, 0.9553f, 0.0f, 3.415658f, 0.01f, RT_MAT_METAL);
+    } else if (keyword == "gold") {
+      currentColor = Color(0.6583748172794485f, 0.4286904966139066f, 0.0382043715953465f);
+      currentMaterial = scene->addMaterial(0.0f, 1.0f, 0.18104f, 0.99f, 0.0f, 3.068099f, 0.01f, RT_MAT_METAL);
+    } else if (keyword == "mirror") {
+      currentColor = Color(0, 0, 0, 0);
+      currentMaterial = scene->addMaterial(0.0f, 1.0f, 0.0f, 0.9f, 0.0f, 0.0f, 0.0f, RT_MAT_MIRROR);
+    } else if (keyword == "diffuse") {
+      currentMaterial = scene->addMaterialDefault();
+    } else if (keyword == "reflective") {
+      // 8-argument constructor with type Dialectric: a material without any lobe (parser.cpp:337-339)
+      currentMaterial = scene->addMaterial(0.0f, 1.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, RT_MAT_DEFAULT);
+    } else if (keyword == "texture") {
+      currentTexture = scene->loadTexture(info.at(1));
+    } else if (keyword == "obj") {
+      std::string objError;
+      if (!loadOBJ(Vec3(f(1), f(2), f(3)), f(4), info.at(5), *scene, currentColor, currentMaterial, objError))
+        scene->log.push_back(objError);  // the reference ignores the failure and carries on
+    }
+    // every other keyword (refractive, gi, shininess, transparency, ...) is silently ignored
+  }
+  scene->camera = camera;
+  scene->options = options;
+  return scene;
+}
+
+// ------------------------------------------------------------------ .sdml
+enum class Tag { Scene, Camera, Light, Shape, Material, Texture, Wavefront, Unknown };
+const char *const kTagNames[] = {"Scene", "Camera", "Light", "Shape", "Material", "Texture", "Wavefront"};
+
+Tag getTagType(const std::string &content) {  // ParserTree.cpp:42-48: content starts with the tag name
+  for (int i = 0; i < 7; ++i)
+    if (content.find(kTagNames[i]) == 0) return static_cast<Tag>(i);
+  return Tag::Unknown;
+}
+
+struct Node {
+  Tag type = Tag::Unknown;
+  std::string content;
+  std::vector<std::unique_ptr<Node>> children;
+};
+
+std::string parseKeyword(const std::string &line, const std::string &keyword) {  // ParserTree.cpp:50-58
+  size_t start = line.find(keyword + "=\"");
+  if (start == std::string::npos) return "";
+  start += keyword.size() + 2;
+  size_t end = line.find('"', start);
+  return line.substr(start, end - start);
+}
+
+using OptionMap = std::unordered_map<std::string, std::string>;
+
+OptionMap parseOptions(const std::string &line) {  // ParserTree.cpp:60-79; the first occurrence of a key wins
+  OptionMap options;
+  size_t start = line.find("options={");
+  if (start == std::string::npos) return options;
+  start += 9;
+  size_t end = line.find('}', start);
+  std::string body = line.substr(start, end == std::string::npos ? std::string::npos : end - start);
+  for (const std::string &option : split(body, ';')) {
+    std::vector<std::string> kv = split(option, ':');
+    if (kv.size() < 2) continue;
+    options.insert({trimCopy(kv[0]), trimCopy(kv[1])});
+  }
+  return options;
+}
+
+Vec3 tupleToVec3(const std::string &s) {  // ParserTree.cpp:81-91: "(x, y, z)"; stof stops at the ')'
+  std::vector<std::string> values = split(s.substr(1, s.size() - 1), ',');
+  return Vec3(std::stof(trimCopy(values.at(0))), std::stof(trimCopy(values.at(1))), std::stof(trimCopy(values.at(2))));
+}
+
+Vec3 optVec3(const OptionMap &o, const std::string &key, const Vec3 &dflt) {
+  auto it = o.find(key);
+  return it != o.end() ? tupleToVec3(it->second) : dflt;
+}
+float optFloat(const OptionMap &o, const std::string &key, float dflt) {
+  auto it = o.find(key);
+  return it != o.end() ? std::stof(it->second) : dflt;
+}
+int optInt(const OptionMap &o, const std::string &key, int dflt) {
+  auto it = o.find(key);
+  return it != o.end() ? std::stoi(it->second) : dflt;
+}
+void overrideColor(const OptionMap &o, Color &color) {  // only r,g,b change; alpha keeps the material's
+  auto it = o.find("color");
+  if (it == o.end()) return;
+  Vec3 t = tupleToVec3(it->second);
+  color.r = t.x; color.g = t.y; color.b = t.z;
+}
+
+void buildTree(std::istream &in, Node *node) {  // ParserTree.cpp:530-561
+  while (true) {
+    std::string line;
+    while (line.empty()) {
+      if (!std::getline(in, line)) return;
+      line = trimCopy(line);
+    }
+    size_t start = line.find('<');
+    size_t end = line.find('>');
+    if (start == std::string::npos || end == std::string::npos || end < start) continue;
+    std::string content = line.substr(start + 1, end - start - 1);
+    if (!content.empty() && content[0] == '/' && node->type == getTagType(content.substr(1))) return;
+    auto child = std::make_unique<Node>();
+    child->type = getTagType(content);
+    if (end == 0 || line[end - 1] != '/') buildTree(in, child.get());
+    else content.pop_back();
+    child->content = content;
+    node->children.push_back(std::move(child));
+  }
+}
+
+struct SdmlLoader {
+  Scene &scene;
+  MaterialBook book;
+  explicit SdmlLoader(Scene &s) : scene(s), book(s) {}
+
+  int parseMaterial(const Node &node, Color &color) {  // ParserTree.cpp:359-409
+    std::string name = parseKeyword(node.content, "name");
+    if (name.empty()) {
+      OptionMap o = parseOptions(node.content);
+      float Kd = optFloat(o, "Kd", 1e-4f), Ks = optFloat(o, "Ks", -1.0f), eta = optFloat(o, "eta", -1.0f);
+      float Kr = optFloat(o, "Kr", -1.0f), Kt = optFloat(o, "Kt", -1.0f), Ka = optFloat(o, "Ka", -1.0f);
+      float roughness = optFloat(o, "roughness", -1.0f);
+      auto it = o.find("type");
+      int type = it != o.end() ? materialTypeByName(it->second) : RT_MAT_DEFAULT;
+      return scene.addMaterial(Kd, Ks, eta, Kr, Kt, Ka, roughness, type);
+    }
+    if (name == "glass") { color = Color(0, 0, 0, 0); return book.get("glass"); }
+    if (name == "plastic") return book.get("plastic");
+    if (name.find("copper") != std::string::npos) { color = materialColors().at(name); return book.get("copper"); }
+    if (name.find("gold") != std::string::npos) { color = materialColors().at(name); return book.get("gold"); }
+    if (name == "mirror") { color = Color(0, 0, 0, 0); return book.get("mirror"); }
+    return book.get("default");
+  }
+
+  void parseShape(const Node &node) {  // ParserTree.cpp:416-458
+    OptionMap o = parseOptions(node.content);
+    std::string type = parseKeyword(node.content, "type");
+    Color color(1, 1, 1, 1);
+    int material = book.get("default");
+    int texture = -1;
+    for (const auto &child : node.children) {
+      if (child->type == Tag::Material) material = parseMaterial(*child, color);
+      else if (child->type == Tag::Texture) texture = scene.loadTexture(parseKeyword(child->content, "path"));
+    }
+    if (type == "sphere") {
+      Vec3 center = optVec3(o, "center", Vec3(0, 0, 0));
+      float radius = optFloat(o, "radius", 1.0f);
+      overrideColor(o, color);
+      scene.addPrim(makeSphere(center, radius, color, material, texture));
+    } else if (type == "triangle") {
+      Vec3 p1 = optVec3(o, "p1", Vec3()), p2 = optVec3(o, "p2", Vec3()), p3 = optVec3(o, "p3", Vec3());
+      Vec3 t1 = optVec3(o, "t1", Vec3()), t2 = optVec3(o, "t2", Vec3()), t3 = optVec3(o, "t3", Vec3());
+      overrideColor(o, color);
+      Prim t = makeTriangle(p1, p2, p3, color, material, t1, t2, t3, texture);
+      orientTriangle(t, scene.camera);
+      scene.addPrim(t);
+    } else if (type == "plane") {
+      Vec3 normal = optVec3(o, "normal", Vec3(0, 0, 0));
+      float D = optFloat(o, "D", 1.0f);
+      Vec3 topLeft = optVec3(o, "top-left", Vec3(0, 0, 0));
+      float zoom = optFloat(o, "texture-zoom", 1.0f);
+      Vec3 shift = optVec3(o, "texture-shift", Vec3(0, 0, 0));
+      overrideColor(o, color);
+      Plane p = makePlane(normal, D, color, material, topLeft, zoom, shift, texture);
+      if (dot(scene.camera.forward, p.normal) > 0) p.normal = -p.normal;  // ParserTree.cpp:449-452
+      scene.planes.push_back(p);
+    }
+  }
+
+  void parseWavefront(const Node &node) {  // ParserTree.cpp:460-488
+    OptionMap o = parseOptions(node.content);
+    std::string path = parseKeyword(node.content, "path");
+    Color color(1, 1, 1, 1);
+    int material = -1;
+    for (const auto &child : node.children)
+      if (child->type == Tag::Material) material = parseMaterial(*child, color);
+    if (material < 0) material = scene.addMaterialDefault();
+    Vec3 center = optVec3(o, "center", Vec3(0, 0, 0));
+    float scale = optFloat(o, "scale", 1.0f);
+    overrideColor(o, color);
+    std::string objError;
+    if (!loadOBJ(center, scale, path, scene, color, material, objError)) scene.log.push_back(objError);
+  }
+
+  void parseLight(const Node &node) {  // ParserTree.cpp:335-357, 105-137
+    OptionMap o = parseOptions(node.content);
+    std::string type = parseKeyword(node.content, "type");
+    Light l;
+    Vec3 c = optVec3(o, "color", Vec3(1, 1, 1));
+    if (type == "distant") {
+      l.type = RT_LIGHT_DISTANT; l.v = optVec3(o, "direction", Vec3(0, 0, 0)); l.color = Color(c.x, c.y, c.z, 1);
+    } else if (type == "point") {
+      l.type = RT_LIGHT_POINT; l.v = optVec3(o, "center", Vec3(0, 0, 0)); l.color = Color(c.x, c.y, c.z, 1);
+    } else if (type == "environment") {
+      l.type = RT_LIGHT_ENVIRONMENT;
+      l.v = scene.worldCenter();
+      l.radius = optFloat(o, "radius", 1.0f);
+      std::string path;
+      if (node.content.find("path") != std::string::npos) path = parseKeyword(node.content, "path");
+      if (path.empty()) {
+        l.color = Color(c.x, c.y, c.z, 1);
+      } else {
+        (void)optFloat(o, "scale", 1.0f);
+        l.color = Color();
+        l.texture = scene.loadTexture(path);
+      }
+    } else {
+      return;
+    }
+    scene.lights.push_back(l);
+  }
+
+  void parseCamera(const Node &node) {  // ParserTree.cpp:320-333
+    OptionMap o = parseOptions(node.content);
+    Camera camera;
+    camera.eye = optVec3(o, "eye", Vec3(0, 0, 0));
+    camera.setForward(optVec3(o, "forward", Vec3(0, 0, -1)));
+    camera.setUp(optVec3(o, "up", Vec3(0, 1, 0)));
+    scene.camera = camera;
+  }
+
+  bool parseScene(Node &root, std::string &error) {  // ParserTree.cpp:258-318
+    OptionMap o = parseOptions(root.content);
+    Options so;
+    so.bias = optFloat(o, "bias", 1e-4f);
+    so.exposure = optFloat(o, "exposure", -1.0f);
+    so.maxBounces = optInt(o, "maxBounces", 4);
+    so.numRays = optInt(o, "numRays", 1);
+    so.fisheye = optInt(o, "fisheye", 0) != 0;
+    so.focus = optFloat(o, "focus", -1.0f);
+    so.lens = (float)optInt(o, "lens", 0);  // the reference parses `lens` with stoi
+    if (!o.count("width")) { error = "Render image width not provided."; return false; }
+    if (!o.count("height")) { error = "Render image height not provided."; return false; }
+    if (!o.count("filename")) { error = "Render image file name not provided."; return false; }
+    scene.width = std::stoi(o["width"]);
+    scene.height = std::stoi(o["height"]);
+    scene.filename = o["filename"];
+    scene.options = so;
+    // lights are parsed after everything else so that worldCenter() is final (ParserTree.cpp:306-317)
+    for (int pass = 0; pass < 2; ++pass) {
+      for (const auto &child : root.children) {
+        bool isLight = child->type == Tag::Light;
+        if (isLight != (pass == 1)) continue;
+        switch (child->type) {
+          case Tag::Camera: parseCamera(*child); break;
+          case Tag::Light: parseLight(*child); break;
+          case Tag::Shape: parseShape(*child); break;
+          case Tag::Wavefront: parseWavefront(*child); break;
+          default: break;
+        }
+      }
+    }
+    return true;
+  }
+};
+
+std::unique_ptr<Scene> readSdml(std::istream &in, std::string &error) {
+  std::string line;
+  std::getline(in, line);
+  size_t start = line.find('<');
+  size_t end = line.find('>');
+  if (start == std::string::npos || end == std::string::npos) { error = "sdml: first line is not a tag"; return nullptr; }
+  Node root;
+  root.content = line.substr(start + 1, end - start - 1);
+  root.type = getTagType(root.content);
+  buildTree(in, &root);
+  auto scene = std::make_unique<Scene>();
+  if (root.type != Tag::Scene) return scene;  // the reference dispatches on the root type and does nothing else
+  SdmlLoader loader(*scene);
+  if (!loader.parseScene(root, error)) return nullptr;
+  return scene;
+}
+
+}  // namespace
+
+bool loadOBJ(const Vec3 &center, float scale, const std::string &filename, Scene &scene, const Color &color,
+             int material, std::string &error) {
+  std::ifstream infile(filename);
+  if (!infile) { error = "Couldn't open file " + filename; return false; }
+  std::vector<Vec3> points, normals;
+  Vec3 extMin(kInf, kInf, kInf), extMax(-kInf, -kInf, -kInf);
+  std::vector<std::string> info;
+  for (std::string line; std::getline(infile, line);) {
+    info = split(line, ' ');
+    if (info.empty()) continue;
+    const std::string &keyword = info[0];
+    if (keyword == "v") {
+      float x = std::stof(info.at(1)), y = std::stof(info.at(2)), z = std::stof(info.at(3));
+      extMin = Vec3(std::min(extMin.x, x), std::min(extMin.y, y), std::min(extMin.z, z));
+      extMax = Vec3(std::max(extMax.x, x), std::max(extMax.y, y), std::max(extMax.z, z));
+      points.emplace_back(x, y, z);
+    } else if (keyword == "vn") {
+      normals.emplace_back(std::stof(info.at(1)), std::stof(info.at(2)), std::stof(info.at(3)));
+    }
+  }
+  // parser.cpp:93-94
+  Vec3 shift = center - (extMax + extMin) / 2;
+  float scaleFactor = scale / maxDimension(extMax - extMin);
+  int numObjects = 0;
+  int numPoints = (int)points.size();
+  infile = std::ifstream(filename);  // second pass over the file, faces only (parser.cpp:96-138)
+  for (std::string line; std::getline(infile, line);) {
+    info = split(line, ' ');
+    if (info.empty() || info[0] != "f") continue;
+    std::vector<int> vertex1 = parseOBJPoint(info.at(1));
+    int i = vertex1.at(0) - 1;
+    for (size_t idx = 2; idx + 1 < info.size(); ++idx) {  // triangle fan
+      std::vector<int> vertex2 = parseOBJPoint(info.at(idx));
+      std::vector<int> vertex3 = parseOBJPoint(info.at(idx + 1));
+      int j = vertex2.at(0) - 1, k = vertex3.at(0) - 1;
+      if (i >= numPoints || j >= numPoints || k >= numPoints) {
+        scene.log.push_back("Indices out of range: " + std::to_string(i) + ' ' + std::to_string(j) + ' ' + std::to_string(k));
+        continue;
+      }
+      Vec3 v1 = scaleFactor * points.at(i) + shift;
+      Vec3 v2 = scaleFactor * points.at(j) + shift;
+      Vec3 v3 = scaleFactor * points.at(k) + shift;
+      Prim t = makeTriangle(v1, v2, v3, color, material);
+      if (vertex1.size() == 3) {  // normals are taken as they are: not transformed, not normalised
+        t.n1 = normals.at(vertex1.at(2) - 1);
+        t.n2 = normals.at(vertex2.at(2) - 1);
+        t.n3 = normals.at(vertex3.at(2) - 1);
+      }
+      scene.addPrim(t);
+      ++numObjects;
+    }
+  }
+  scene.log.push_back("Scanned " + std::to_string(points.size()) + " points and " + std::to_string(numObjects) + " objects");
+  return true;
+}
+
+std::unique_ptr<Scene> readFromFile(const std::string &filename, std::string &error) {  // parser.cpp:362-378
+  std::ifstream infile(filename);
+  if (!infile) { error = "Couldn't open file " + filename; return nullptr; }
+  try {
+    if (endsWith(filename, ".txt")) return readTxt(infile, error);
+    if (endsWith(filename, ".sdml")) return readSdml(infile, error);
+  } catch (const std::exception &e) {
+    // The reference lets std::stof/stoi/at() exceptions escape and aborts; report them instead.
+    error = std::string("malformed scene file: ") + e.what();
+    return nullptr;
+  }
+  error = "Unrecognized file format " + filename;
+  return nullptr;
+}
+
+}  // namespace rth

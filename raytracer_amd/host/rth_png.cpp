@@ -1,0 +1,209 @@
+// Minimal PNG codec on top of zlib. The reference uses LodePNG (src/image/lodepng.*) only to
+// turn a file into 8-bit RGBA and back (src/image/PNG.cpp:125-165); what has to match is the
+// pixels, not the file bytes. Colour handling around it (÷255, sRGB <-> linear with the
+// reference's double-precision pow) is restated from src/image/PNG.cpp:7-30.
+#include <zlib.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "rth_scene.h"
+
+namespace rth {
+namespace {
+
+uint32_t be32(const uint8_t *p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
+void put32(std::vector<uint8_t> &v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
+
+int paeth(int a, int b, int c) {
+  int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+  if (pa <= pb && pa <= pc) return a;
+  return pb <= pc ? b : c;
+}
+
+// src/image/PNG.cpp:14-18 — float argument, double constants, result narrowed to float
+float gammaToLinear(float channel) {
+  if (channel < 0.04045) return channel / 12.92;
+  return std::pow((channel + 0.055) / 1.055, 2.4);
+}
+// src/image/PNG.cpp:7-12
+float linearToGamma(float channel) {
+  if (channel < 0.0031308) return 12.92 * channel;
+  return 1.055 * std::pow(channel, 1 / 2.4) - 0.055;
+}
+
+}  // namespace
+
+bool decodePNG8(const std::string &filename, int &w, int &h, std::vector<uint8_t> &rgba8, std::string &error) {
+  FILE *f = std::fopen(filename.c_str(), "rb");
+  if (!f) { error = "failed to open file for reading: " + filename; return false; }
+  std::vector<uint8_t> file;
+  uint8_t buf[65536];
+  size_t got;
+  while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + got);
+  std::fclose(f);
+  static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
+  if (file.size() < 33 || std::memcmp(file.data(), sig, 8) != 0) { error = "not a PNG file: " + filename; return false; }
+  size_t pos = 8;
+  int bitDepth = 0, colorType = 0, interlace = 0;
+  std::vector<uint8_t> idat, palette, trns;
+  bool seenIHDR = false;
+  while (pos + 12 <= file.size()) {
+    uint32_t len = be32(&file[pos]);
+    if (pos + 12 + (size_t)len > file.size()) { error = "truncated PNG chunk"; return false; }
+    const uint8_t *type = &file[pos + 4];
+    const uint8_t *data = &file[pos + 8];
+    if (!std::memcmp(type, "IHDR", 4)) {
+      if (len != 13) { error = "bad IHDR"; return false; }
+      w = (int)be32(data); h = (int)be32(data + 4);
+      bitDepth = data[8]; colorType = data[9]; interlace = data[12];
+      seenIHDR = true;
+    } else if (!std::memcmp(type, "PLTE", 4)) palette.assign(data, data + len);
+    else if (!std::memcmp(type, "tRNS", 4)) trns.assign(data, data + len);
+    else if (!std::memcmp(type, "IDAT", 4)) idat.insert(idat.end(), data, data + len);
+    else if (!std::memcmp(type, "IEND", 4)) break;
+    pos += 12 + (size_t)len;
+  }
+  if (!seenIHDR || w <= 0 || h <= 0) { error = "PNG without a valid IHDR"; return false; }
+  if (interlace != 0) { error = "interlaced PNG is not supported"; return false; }
+  int channels;
+  switch (colorType) {
+    case 0: channels = 1; break;
+    case 2: channels = 3; break;
+    case 3: channels = 1; break;
+    case 4: channels = 2; break;
+    case 6: channels = 4; break;
+    default: error = "bad PNG colour type"; return false;
+  }
+  int bitsPerPixel = channels * bitDepth;
+  size_t rowBytes = ((size_t)w * bitsPerPixel + 7) / 8;
+  int bpp = std::max(1, bitsPerPixel / 8);
+  std::vector<uint8_t> raw((rowBytes + 1) * (size_t)h);
+  uLongf rawLen = (uLongf)raw.size();
+  int zr = uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size());
+  if (zr != Z_OK || rawLen != raw.size()) { error = "PNG inflate failed"; return false; }
+  // undo the per-row filters in place
+  std::vector<uint8_t> prev(rowBytes, 0), cur(rowBytes);
+  std::vector<uint8_t> pix(rowBytes * (size_t)h);
+  for (int y = 0; y < h; ++y) {
+    const uint8_t *row = &raw[(rowBytes + 1) * (size_t)y];
+    int ft = row[0];
+    for (size_t i = 0; i < rowBytes; ++i) {
+      int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= (size_t)bpp ? prev[i - bpp] : 0;
+      int x = row[1 + i];
+      switch (ft) {
+        case 0: break;
+        case 1: x += a; break;
+        case 2: x += b; break;
+        case 3: x += (a + b) >> 1; break;
+        case 4: x += paeth(a, b, c); break;
+        default: error = "bad PNG filter type"; return false;
+      }
+      cur[i] = (uint8_t)x;
+    }
+    std::memcpy(&pix[rowBytes * (size_t)y], cur.data(), rowBytes);
+    prev.swap(cur);
+  }
+  rgba8.assign((size_t)w * h * 4, 255);
+  auto sample = [&](const uint8_t *row, int idx) -> unsigned {  // idx-th sample of the row, full bit depth
+    if (bitDepth == 8) return row[idx];
+    if (bitDepth == 16) return (unsigned)row[idx * 2] << 8 | row[idx * 2 + 1];
+    int bitPos = idx * bitDepth;
+    return (row[bitPos >> 3] >> (8 - bitDepth - (bitPos & 7))) & ((1u << bitDepth) - 1);
+  };
+  unsigned maxv = (1u << bitDepth) - 1;
+  auto to8 = [&](unsigned v) -> uint8_t {
+    if (bitDepth == 8) return (uint8_t)v;
+    if (bitDepth == 16) return (uint8_t)(v >> 8);
+    return (uint8_t)((v * 255u) / maxv);
+  };
+  for (int y = 0; y < h; ++y) {
+    const uint8_t *row = &pix[rowBytes * (size_t)y];
+    for (int x = 0; x < w; ++x) {
+      uint8_t *o = &rgba8[((size_t)y * w + x) * 4];
+      if (colorType == 0) {
+        unsigned g = sample(row, x);
+        o[0] = o[1] = o[2] = to8(g);
+        if (trns.size() >= 2 && g == ((unsigned)trns[0] << 8 | trns[1])) o[3] = 0;
+      } else if (colorType == 2) {
+        unsigned r = sample(row, x * 3), g = sample(row, x * 3 + 1), b = sample(row, x * 3 + 2);
+        o[0] = to8(r); o[1] = to8(g); o[2] = to8(b);
+        if (trns.size() >= 6 && r == ((unsigned)trns[0] << 8 | trns[1]) && g == ((unsigned)trns[2] << 8 | trns[3]) &&
+            b == ((unsigned)trns[4] << 8 | trns[5])) o[3] = 0;
+      } else if (colorType == 3) {
+        unsigned i = sample(row, x);
+        if ((size_t)i * 3 + 2 < palette.size()) { o[0] = palette[i * 3]; o[1] = palette[i * 3 + 1]; o[2] = palette[i * 3 + 2]; }
+        else { o[0] = o[1] = o[2] = 0; }
+        if (i < trns.size()) o[3] = trns[i];
+      } else if (colorType == 4) {
+        o[0] = o[1] = o[2] = to8(sample(row, x * 2)); o[3] = to8(sample(row, x * 2 + 1));
+      } else {
+        o[0] = to8(sample(row, x * 4)); o[1] = to8(sample(row, x * 4 + 1));
+        o[2] = to8(sample(row, x * 4 + 2)); o[3] = to8(sample(row, x * 4 + 3));
+      }
+    }
+  }
+  return true;
+}
+
+bool readPNG(const std::string &filename, Image &out, std::string &error) {
+  std::vector<uint8_t> bytes;
+  if (!decodePNG8(filename, out.width, out.height, bytes, error)) return false;
+  out.rgba.resize(bytes.size());
+  // src/image/PNG.cpp:137-144: byte / 255.0f, then toLinear on r,g,b (alpha untouched)
+  for (size_t i = 0; i < bytes.size(); i += 4) {
+    out.rgba[i + 0] = gammaToLinear(bytes[i + 0] / 255.0f);
+    out.rgba[i + 1] = gammaToLinear(bytes[i + 1] / 255.0f);
+    out.rgba[i + 2] = gammaToLinear(bytes[i + 2] / 255.0f);
+    out.rgba[i + 3] = bytes[i + 3] / 255.0f;
+  }
+  return true;
+}
+
+void toSRGB8(const float *rgba, size_t numPixels, uint8_t *rgba8) {
+  // src/image/PNG.cpp:151-157: toSRGB on r,g,b; static_cast<unsigned char>(round(x * 255))
+  for (size_t i = 0; i < numPixels; ++i) {
+    float r = linearToGamma(rgba[i * 4 + 0]), g = linearToGamma(rgba[i * 4 + 1]), b = linearToGamma(rgba[i * 4 + 2]);
+    float a = rgba[i * 4 + 3];
+    rgba8[i * 4 + 0] = static_cast<unsigned char>(std::round(r * 255));
+    rgba8[i * 4 + 1] = static_cast<unsigned char>(std::round(g * 255));
+    rgba8[i * 4 + 2] = static_cast<unsigned char>(std::round(b * 255));
+    rgba8[i * 4 + 3] = static_cast<unsigned char>(std::round(a * 255));
+  }
+}
+
+bool writePNG8(const std::string &filename, int w, int h, const uint8_t *rgba8, std::string &error) {
+  std::vector<uint8_t> raw((size_t)h * ((size_t)w * 4 + 1));
+  for (int y = 0; y < h; ++y) {
+    uint8_t *row = &raw[(size_t)y * ((size_t)w * 4 + 1)];
+    row[0] = 0;  // filter type None
+    std::memcpy(row + 1, rgba8 + (size_t)y * w * 4, (size_t)w * 4);
+  }
+  uLongf clen = compressBound((uLong)raw.size());
+  std::vector<uint8_t> comp(clen);
+  if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) != Z_OK) { error = "PNG deflate failed"; return false; }
+  comp.resize(clen);
+  std::vector<uint8_t> out = {137, 80, 78, 71, 13, 10, 26, 10};
+  auto chunk = [&](const char *type, const std::vector<uint8_t> &data) {
+    put32(out, (uint32_t)data.size());
+    size_t start = out.size();
+    out.insert(out.end(), type, type + 4);
+    out.insert(out.end(), data.begin(), data.end());
+    put32(out, (uint32_t)crc32(0, &out[start], (uInt)(out.size() - start)));
+  };
+  std::vector<uint8_t> ihdr;
+  put32(ihdr, (uint32_t)w); put32(ihdr, (uint32_t)h);
+  ihdr.push_back(8); ihdr.push_back(6); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+  chunk("IHDR", ihdr);
+  chunk("IDAT", comp);
+  chunk("IEND", {});
+  FILE *f = std::fopen(filename.c_str(), "wb");
+  if (!f) { error = "failed to open file for writing: " + filename; return false; }
+  bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();
+  std::fclose(f);
+  if (!ok) error = "short write: " + filename;
+  return ok;
+}
+
+}  // namespace rth
