@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s and frame wall-time of the README-scene stand-in (1080x1080, 256 camera samples per
+pixel, ~1.05 M triangles + 2 textured spheres + 3 textured planes, point + environment light, maxBounces 4).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step is one whole frame through the C ABI (rt_render): scene and BVH already resident in HBM, the frame left in a
+device buffer. With N > 1 every rank renders its interleaved 32x32 tiles of the SAME frame (total work fixed: strong
+scaling) and the tiles are combined on rank 0 by an RCCL reduce over xGMI (pixels outside a rank's tiles are exactly 0).
+"ray" = one BVH traversal query (Scene::findClosestObject / findAnyObject in the reference): camera, bounce and shadow
+rays alike. Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=256, help="camera samples per pixel (numRays)")
+    ap.add_argument("--size", type=int, default=1080)
+    ap.add_argument("--grid", type=int, default=512, help="cells per side of the largest mesh (512 -> ~1.05 M triangles)")
+    ap.add_argument("--spp-pass", type=int, default=0)
+    ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample; 0 disables it")
+    ap.add_argument("--scene-dir", default=None)
+    return ap.parse_args()
+
+
+def scene_files(args, rank, barrier):
+    """The scene as FILES the reference's own parsers read (sdml + OBJ with vn + PNG textures), generated once."""
+    from tools import gen_scenes
+    d = args.scene_dir or f"/tmp/rt_bench_scene_{args.size}_{args.spp}_{args.grid}"
+    marker = os.path.join(d, "readme.sdml.done")
+    if rank == 0 and not os.path.exists(marker):
+        os.makedirs(d, exist_ok=True)
+        gen_scenes.scene_readme(d, "readme", size=args.size, spp=args.spp, grid=(args.grid, args.grid),
+                                texsize=512 if args.grid >= 256 else 128)
+        open(marker, "w").write("ok\n")
+    barrier()
+    return os.path.join(d, "readme.sdml")
+
+
+def bytes_per_ray(inner, prims, rays):
+    """Algorithmic bytes of one traversal query: 32 B ray in + 64 B per inner-node expansion (two child boxes) +
+    48 B per primitive test + 16 B hit record out."""
+    if rays == 0:
+        return 0.0
+    return 32.0 + 64.0 * inner / rays + 48.0 * prims / rays + 16.0
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render loop has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    from raytracer_amd import capi
+
+    t_setup = time.time()
+    path = scene_files(args, rank, barrier)
+    hs = capi.HostScene.load(path).build()
+    desc = hs.desc
+    d = desc.contents
+    dev = capi.device_scene(desc, device=local_rank)
+    W, H = d.options.width, d.options.height
+    out = torch.zeros((H, W, 4), dtype=torch.float32, device=torch.device("cuda", local_rank))
+    setup_s = time.time() - t_setup
+
+    def step():
+        _, st = dev.render(seed=56, part_index=rank, part_count=world, tile=(args.tile, args.tile),
+                           samples_per_pass=args.spp_pass, out_ptr=out.data_ptr())
+        if world > 1:
+            dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
+        return st
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stats = [step() for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    rays_local = sum(s.raysClosest + s.raysAny for s in stats)
+    samples_local = sum(s.cameraSamples for s in stats)
+    agg = torch.tensor([float(elapsed), float(rays_local), float(samples_local)], dtype=torch.float64,
+                       device=torch.device("cuda", local_rank))
+    if world > 1:
+        tmax = agg[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        sums = agg[1:].clone()
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        elapsed, rays_total, samples_total = float(tmax[0]), float(sums[0]), float(sums[1])
+    else:
+        rays_total, samples_total = float(rays_local), float(samples_local)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    mrays = rays_total / elapsed / 1e6
+
+    # ---- roofline of the dominant kernel: per-ray work counted by the kernels themselves on a few samples per pixel,
+    # kernel time from the HIP events the library records around each launch of the timed steps.
+    import ctypes as C
+    o = d.options
+    few = capi.RtOptions(o.width, o.height, o.bias, o.exposure, o.maxBounces, min(4, o.numRays), o.fisheye, o.focus, o.lens)
+    full = capi.RtOptions(o.width, o.height, o.bias, o.exposure, o.maxBounces, o.numRays, o.fisheye, o.focus, o.lens)
+    dev.set_view(options=few)
+    _, cst = dev.render(seed=56, part_index=rank, part_count=world, tile=(args.tile, args.tile), collect_counters=True, download=False)
+    dev.set_view(options=full)
+    b_ext = bytes_per_ray(cst.innerExtend, cst.primExtend, cst.raysExtend)
+    b_sh = bytes_per_ray(cst.innerShadow, cst.primShadow, cst.raysShadow)
+    ms_ext = sum(s.msExtend for s in stats); ms_sh = sum(s.msShadow for s in stats)
+    rays_ext = sum(s.raysExtend for s in stats); rays_sh = sum(s.raysShadow for s in stats)
+    launches_ext = sum(s.launchesExtend for s in stats); launches_sh = sum(s.launchesShadow for s in stats)
+    if ms_ext >= ms_sh:
+        kname, kb, kms, krays, klaunch = "k_extend", b_ext, ms_ext, rays_ext, launches_ext
+    else:
+        kname, kb, kms, krays, klaunch = "k_shadow", b_sh, ms_sh, rays_sh, launches_sh
+    achieved = (krays * kb) / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    roofline = {
+        "bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        "bytes_per_ray": round(kb, 1), "rays_per_launch": round(krays / max(1, klaunch), 1),
+        "avg_launch_ms": round(kms / max(1, klaunch), 4), "mrays_per_s_in_kernel": round(krays / (kms * 1e-3) / 1e6, 1) if kms > 0 else 0.0,
+        "other_kernel": {"kernel": "k_shadow" if kname == "k_extend" else "k_extend",
+                         "bytes_per_ray": round(b_sh if kname == "k_extend" else b_ext, 1),
+                         "ms_total": round(ms_sh if kname == "k_extend" else ms_ext, 2),
+                         "rays": int(rays_sh if kname == "k_extend" else rays_ext)},
+    }
+
+    # ---- CPU baseline: the CPU restatement of the reference's loop on this box's host cores, bounded sample.
+    cpu = None
+    if args.cpu_seconds > 0 and world == 1:
+        from tests.oracle_binding import oracle_scene
+        cores = min(16, len(os.sched_getaffinity(0)))
+        orc = oracle_scene(desc, threads=cores)
+        one = capi.RtOptions(o.width, o.height, o.bias, o.exposure, o.maxBounces, 1, o.fisheye, o.focus, o.lens)
+        orc.set_view(options=one)
+        t = time.perf_counter(); _, ost = orc.render(seed=56); t1 = time.perf_counter() - t
+        spp_cpu = int(max(1, min(16, args.cpu_seconds / max(t1, 1e-3))))
+        if spp_cpu > 1:
+            orc.set_view(options=capi.RtOptions(o.width, o.height, o.bias, o.exposure, o.maxBounces, spp_cpu, o.fisheye, o.focus, o.lens))
+            t = time.perf_counter(); _, ost = orc.render(seed=56); t1 = time.perf_counter() - t
+        cpu_rays = ost.raysClosest + ost.raysAny
+        cpu = {"value": round(cpu_rays / t1 / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+               "sample": f"same scene and resolution, {spp_cpu} of {o.numRays} samples per pixel, {cpu_rays} rays in {t1:.1f} s "
+                         f"(CPU restatement of the reference loop, {cores} threads)"}
+        orc.close()
+
+    tris = int(d.numPrims)
+    line = {
+        "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"README-scene stand-in: {W}x{H}, {o.numRays} spp, {tris} BVH objects + {d.numPlanes} planes, "
+                               f"point + environment light, maxBounces {o.maxBounces}",
+                   "width": W, "height": H, "spp": o.numRays, "objects": tris, "bvh_nodes": int(d.numNodes),
+                   "parallelism": f"image tiles {args.tile}x{args.tile} interleaved over {world} GPU(s), RCCL reduce to rank 0"},
+        "wall_time_s": round(ms_per_step / 1e3, 3),
+        "camera_msamples_per_s": round(samples_total / elapsed / 1e6, 2),
+        "rays_per_frame": int(rays_total / args.steps),
+        "rays_per_camera_sample": round(rays_total / max(1.0, samples_total), 3),
+        "kernel_ms_per_frame": {k: round(sum(getattr(s, k) for s in stats) / args.steps, 2)
+                                for k in ("msTotal", "msRaygen", "msExtend", "msShade", "msShadow", "msAccumulate", "msResolve")},
+        "setup_s": round(setup_s, 1),
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -143,9 +143,13 @@ typedef struct RtStats {
   uint64_t cameraSamples;
   uint64_t raysClosest;    /* Scene::findClosestObject-equivalent queries from the path loop + point lights */
   uint64_t raysAny;        /* Scene::findAnyObject-equivalent queries (distant / environment lights) */
-  uint64_t innerExpansions;/* only with collectCounters */
-  uint64_t primTests;      /* only with collectCounters */
-  uint64_t planeTests;
+  uint64_t innerExpansions;/* only with collectCounters: inner-node expansions (two child boxes each), all queries */
+  uint64_t primTests;      /* only with collectCounters: triangle/sphere tests, all queries */
+  uint64_t planeTests;     /* only with collectCounters */
+  uint64_t raysExtend;     /* queries traced by the path-extension kernel (one per live path per bounce) */
+  uint64_t raysShadow;     /* queries traced by the light-visibility kernel (one per light per hit) */
+  uint64_t innerExtend, primExtend;   /* the two counters above, split by kernel (only with collectCounters) */
+  uint64_t innerShadow, primShadow;
   double msTotal;          /* render phase, device-side (HIP events on the library's stream) */
   double msRaygen, msExtend, msShade, msShadow, msDirect, msAccumulate, msResolve;
   uint32_t launchesExtend, launchesShadow;
@@ -182,8 +186,9 @@ int rt_trace_any(RtScene *scene, int64_t n, const float *origins, const float *d
 /* The whole of Scene::render's pixel loop (src/scene/raytracer.cpp:253-285 with the worker chosen at :290-299):
  * writes the clipped (and, unless skipExposure, exposed) linear float RGBA framebuffer, row-major
  * width*height*4 floats, i.e. the contents of the PNG object Scene::render returns. Pixels outside this
- * call's tile partition are written as 0. rgbaOut may be NULL (result stays on the device, see
- * rt_framebuffer_device). stats may be NULL. */
+ * call's tile partition are written as 0. rgbaOut may be a host pointer or a device pointer of the same device
+ * (the copy is made with hipMemcpyDefault), or NULL (result stays on the device, see rt_framebuffer_device).
+ * stats may be NULL. */
 int rt_render(RtScene *scene, const RtRenderParams *params, float *rgbaOut, RtStats *stats);
 
 /* Device pointer of the float RGBA framebuffer of the last rt_render on this scene (width*height*4 floats). */

@@ -146,9 +146,10 @@ struct Lobe {
 struct Material { int type; std::vector<Lobe> lobes; };
 
 struct Counters {
-  uint64_t raysClosest = 0, raysAny = 0, inner = 0, prims = 0, planes = 0, samples = 0;
+  uint64_t raysClosest = 0, raysAny = 0, inner = 0, prims = 0, planes = 0, samples = 0, raysExtend = 0;
   void add(const Counters &o) {
     raysClosest += o.raysClosest; raysAny += o.raysAny; inner += o.inner; prims += o.prims; planes += o.planes; samples += o.samples;
+    raysExtend += o.raysExtend;
   }
 };
 
@@ -670,6 +671,7 @@ RGBA raytrace(const RtoScene &s, const V3 &origin, const V3 &direction, Sampler 
   V3 rayOrigin = origin;
   V3 rayDirection = direction;
   for (int bounces = 0; bounces < s.options.maxBounces; ++bounces) {
+    ++ctr().raysExtend;
     Hit info = findClosestObject(s, rayOrigin, rayDirection);
     if (info.prim < 0) {
       for (const RtLight &l : s.lights) addAssign(L, emittedLight(s, l, rayDirection));
@@ -954,6 +956,8 @@ int rto_render(RtoScene *s, const RtRenderParams *params, float *rgbaOut, RtStat
     stats->innerExpansions = total.inner;
     stats->primTests = total.prims;
     stats->planeTests = total.planes;
+    stats->raysExtend = total.raysExtend;
+    stats->raysShadow = total.raysClosest + total.raysAny - total.raysExtend;
   }
   return RT_OK;
 }

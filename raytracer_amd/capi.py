@@ -81,6 +81,8 @@ class RtRenderParams(C.Structure):
 class RtStats(C.Structure):
     _fields_ = [("cameraSamples", C.c_uint64), ("raysClosest", C.c_uint64), ("raysAny", C.c_uint64),
                 ("innerExpansions", C.c_uint64), ("primTests", C.c_uint64), ("planeTests", C.c_uint64),
+                ("raysExtend", C.c_uint64), ("raysShadow", C.c_uint64), ("innerExtend", C.c_uint64),
+                ("primExtend", C.c_uint64), ("innerShadow", C.c_uint64), ("primShadow", C.c_uint64),
                 ("msTotal", C.c_double), ("msRaygen", C.c_double), ("msExtend", C.c_double), ("msShade", C.c_double),
                 ("msShadow", C.c_double), ("msDirect", C.c_double), ("msAccumulate", C.c_double),
                 ("msResolve", C.c_double), ("launchesExtend", C.c_uint32), ("launchesShadow", C.c_uint32),
@@ -236,6 +238,7 @@ class HostScene:
         d = self._L.rth_scene_desc(self._h)
         if not d:
             raise RuntimeError("rth_scene_desc: " + self._L.rth_last_error().decode())
+        d._owner = self  # the arrays behind the description live in this scene
         return d
 
     @property
@@ -372,12 +375,21 @@ class RenderScene:
         return occ
 
     def render(self, rng_mode=RT_RNG_COUNTER, seed=56, part_index=0, part_count=1, tile=(32, 32), samples_per_pass=0,
-               collect_counters=False, skip_exposure=False, download=True):
+               collect_counters=False, skip_exposure=False, download=True, out_ptr=None):
+        """out_ptr: optional raw pointer (host or device memory of width*height*4 floats) that receives the frame
+        instead of a fresh numpy array."""
         p = RtRenderParams(rng_mode, seed, part_index, part_count, tile[0], tile[1], samples_per_pass,
                            int(collect_counters), int(skip_exposure))
         st = RtStats()
-        out = np.empty((self.height, self.width, 4), dtype=np.float32) if download else None
-        self._check(self._f("render")(self._h, C.byref(p), None if out is None else _fp(out), C.byref(st)), "render")
+        out = None
+        if out_ptr is not None:
+            dst = C.cast(C.c_void_p(out_ptr), C.POINTER(C.c_float))
+        elif download:
+            out = np.empty((self.height, self.width, 4), dtype=np.float32)
+            dst = _fp(out)
+        else:
+            dst = None
+        self._check(self._f("render")(self._h, C.byref(p), dst, C.byref(st)), "render")
         return out, st
 
     def framebuffer_device(self):

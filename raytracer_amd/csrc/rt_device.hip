@@ -1,0 +1,1065 @@
+// libraytracer_amd.so — the render loop of RichardXiao13/Raytracer as a wavefront path tracer for gfx950 (MI355X),
+// behind the C ABI of include/rt_amd.h.
+//
+// One frame = passes of P paths (camera samples). A path owns one slot of SoA state in HBM for the whole pass; the
+// kernels below are launched once per bounce over index queues of live slots:
+//
+//   k_raygen      Scene::threadTaskDefault/Fisheye/DOF sample set-up (src/scene/raytracer.cpp:44-47, 92-103, 142-153)
+//   k_extend      Scene::findClosestObject for every live path (src/scene/raytracer.cpp:216)           <- traversal
+//   k_shade       miss -> environment; hit -> geometry, getColor, light sampling set-up, BSDF sample (:217-246)
+//   k_shadow      the visibility queries of Light::intensity (src/scene/Object.cpp:7-46) + L += beta * ...  <- traversal
+//   k_advance     queue bookkeeping and ray counters
+//   k_accumulate  per-pixel sample average bookkeeping (:48-51), in sample order
+//   k_resolve     hits/alpha/clip (:54-59) and Scene::expose (:303-312) into the float RGBA framebuffer
+//
+// Built with -ffp-contract=off: primary hit ids and t bits are compared bit-for-bit with the CPU path.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "rt_amd.h"
+#include "rt_dev_shade.h"
+#include "rt_dev_traverse.h"
+
+using namespace rtd;
+
+namespace {
+
+constexpr int kBlock = 256;       // 4 wavefronts
+constexpr int kStackLds = 8;      // stack entries per lane kept in LDS (8 B each -> 16 KiB per block)
+
+struct Counts {
+  uint32_t nActive, nNext, nHit, stackOverflow;
+  unsigned long long raysClosest, raysAny, samples, raysExtend, raysShadow;
+  unsigned long long inner[2], prims[2], planes[2];  // [0] path extension, [1] light visibility
+};
+
+struct PathBuf {
+  float4 *rayO, *rayD, *beta, *L;
+  uint32_t *rng;
+  float *hitT;
+  int32_t *hitPrim;
+  float4 *shPoint, *shNormal, *shColor, *shWeight;
+  float4 *envWi;  // [numEnvLights][P]
+  uint32_t *qA, *qB, *qHit;
+  Counts *counts;
+  int32_t P, npix;
+};
+
+// Appends the lanes with `pred` to a queue with one atomic per wavefront; lane order is kept inside the wavefront.
+// Must be reached by every lane of the wavefront.
+RT_DEV uint32_t queueSlot(uint32_t *counter, bool pred) {
+  unsigned long long mask = __ballot(pred);
+  if (mask == 0ull) return 0u;
+  uint32_t lane = __lane_id();
+  int leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+  base = __shfl(base, leader);
+  return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+template <bool COUNT>
+RT_DEV void flushCounters(Counts *c, const TravCounters &tc, bool overflow, int kind) {
+  if (COUNT) {
+    // wave reduction, then one atomic per wavefront and counter
+    unsigned long long a = tc.inner, b = tc.prims, p = tc.planes;
+    for (int off = 32; off > 0; off >>= 1) {
+      a += __shfl_down(a, off); b += __shfl_down(b, off); p += __shfl_down(p, off);
+    }
+    if (__lane_id() == 0) { atomicAdd(&c->inner[kind], a); atomicAdd(&c->prims[kind], b); atomicAdd(&c->planes[kind], p); }
+  }
+  if (overflow) atomicOr(&c->stackOverflow, 1u);
+}
+
+RT_DEV float getRayScaleX(float x, int w, int h) { return (2 * x - w) / max(w, h); }  // src/scene/raytracer.cpp:13-15
+RT_DEV float getRayScaleY(float y, int w, int h) { return (h - 2 * y) / max(w, h); }  // :17-19
+
+// ---------------------------------------------------------------------------------------------------- k_raygen
+__global__ __launch_bounds__(kBlock) void k_raygen(DevScene S, PathBuf B, const int32_t *pixList, int32_t sampleBase,
+                                                   int32_t sppThis, uint32_t seed) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  bool valid = i < (int64_t)B.npix * sppThis;
+  bool alive = false;
+  if (valid) {
+    int32_t p = (int32_t)(i % B.npix), s = (int32_t)(i / B.npix);
+    int32_t pixel = pixList[p];
+    int32_t x = pixel % S.width, y = pixel / S.width;
+    uint32_t rng = rngSeed(seed, (uint32_t)pixel, (uint32_t)(sampleBase + s));
+    int allowAA = min(1, S.numRays - 1);
+    float Sx = getRayScaleX(x + (rngNext(rng) - 0.5f) * allowAA, S.width, S.height);
+    float Sy = getRayScaleY(y + (rngNext(rng) - 0.5f) * allowAA, S.width, S.height);
+    V3 eye = v3(S.eye), forward = v3(S.forward), right = v3(S.right), up = v3(S.up);
+    V3 o = eye, d;
+    alive = true;
+    if (S.cameraMode == 0) {
+      d = forward + Sx * right + Sy * up;
+    } else if (S.cameraMode == 1) {  // fisheye, raytracer.cpp:95-103
+      Sx *= S.invForwardLength;
+      Sy *= S.invForwardLength;
+      float r_2 = Sx * Sx + Sy * Sy;
+      if (r_2 > 1) alive = false;  // `continue`: the sample neither traces nor counts
+      V3 forwardCopy = sqrtf(1 - r_2) * v3(S.normalizedForward);
+      d = forwardCopy + Sx * right + Sy * up;
+    } else {  // depth of field, raytracer.cpp:144-151
+      V3 rayDirection = forward + Sx * right + Sy * up;
+      V3 focusPoint = (S.focus / magnitude(rayDirection)) * rayDirection + eye;
+      float weight = (float)((double)(rngNext(rng) * 2) * kPi);
+      float r = rngNext(rng) - 0.5f;
+      o = (r * cosf(weight) * S.lens / S.magRight) * right + (r * sinf(weight) * S.lens / S.magUp) * up + eye;
+      d = focusPoint - o;
+    }
+    B.rng[i] = rng;
+    B.L[i] = make_float4(0, 0, 0, 0);
+    B.beta[i] = make_float4(1, 1, 1, 1);
+    if (alive) {
+      B.rayO[i] = make_float4(o.x, o.y, o.z, 0);
+      B.rayD[i] = make_float4(d.x, d.y, d.z, 0);
+    }
+  }
+  uint32_t q = queueSlot(&B.counts->nActive, alive);
+  if (alive) B.qA[q] = (uint32_t)i;
+}
+
+// ---------------------------------------------------------------------------------------------------- k_extend
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_extend(DevScene S, PathBuf B, const uint32_t *queue) {
+  __shared__ uint2 ldsStack[kStackLds * kBlock];
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  TravCounters tc = {0, 0, 0};
+  bool overflow = false;
+  if (i < B.counts->nActive) {
+    uint32_t slot = queue[i];
+    float4 o = B.rayO[slot], d = B.rayD[slot];
+    HitRec h = traverse<false, COUNT, kStackLds, kBlock>(S, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), ldsStack, tc, overflow);
+    B.hitT[slot] = h.t;
+    B.hitPrim[slot] = h.prim;
+  }
+  flushCounters<COUNT>(B.counts, tc, overflow, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------- k_shade
+__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, PathBuf B, const uint32_t *queue, uint32_t *queueNext,
+                                                  int32_t bounce) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  bool isHit = false, continues = false;
+  uint32_t slot = 0;
+  if (i < B.counts->nActive) {
+    slot = queue[i];
+    float4 o4 = B.rayO[slot], d4 = B.rayD[slot];
+    V3 o = v3(o4.x, o4.y, o4.z), d = v3(d4.x, d4.y, d4.z);
+    int32_t prim = B.hitPrim[slot];
+    if (prim < 0) {
+      // miss: add every light's emittedLight(direction) (raytracer.cpp:217-223); only environment lights emit
+      RGBA L = rgba(B.L[slot]);
+      for (int k = 0; k < S.numLights; ++k) addAssign(L, emittedLight(S, S.lights[k], d));
+      B.L[slot] = f4(L);
+    } else {
+      isHit = true;
+      float t = B.hitT[slot];
+      V3 nd = normalized(d);
+      V3 point = t * nd + o;  // IntersectionInfo::point as the primitive computed it
+      V3 normal;
+      int32_t matIdx;
+      RGBA objColor;
+      if (prim >= S.numPrims) {
+        const DevPlane &pl = S.planes[prim - S.numPrims];
+        normal = v3(pl.normal);
+        matIdx = pl.material;
+        objColor = rgba(pl.color[0], pl.color[1], pl.color[2], pl.color[3]);
+      } else {
+        const float4 *P = S.primHit + 3 * (int64_t)prim;
+        float4 a = P[0], b = P[1], c = P[2];
+        bool sphere = (__float_as_uint(a.w) | __float_as_uint(b.x) | __float_as_uint(b.y)) == 0u;
+        if (sphere) {
+          normal = normalized(point - v3(a.x, a.y, a.z));  // Object.cpp:98
+        } else {
+          // shading normal from the barycentrics, Object.cpp:206-212
+          V3 p1 = v3(a.x, a.y, a.z), e1 = v3(b.z, b.w, c.x), e2 = v3(c.y, c.z, c.w);
+          V3 q = point - p1;
+          float b2 = dot(e1, q);
+          float b3 = dot(e2, q);
+          float b1 = 1.0f - b3 - b2;
+          const float *nn = S.primNormals + 9 * (int64_t)prim;
+          normal = normalized(v3(nn) * b1 + v3(nn + 3) * b2 + v3(nn + 6) * b3);
+        }
+        matIdx = S.primMaterial[prim];
+        objColor = rgba(S.primColor[prim]);
+      }
+      V3 wo = -nd;
+      V3 outNormal = faceForward(wo, normal);
+      V3 biased = point + S.bias * outNormal;  // raytracer.cpp:228
+      uint32_t rng = B.rng[slot];
+      RGBA beta = rgba(B.beta[slot]);
+      // Inputs of the direct-light term, consumed by k_shadow: L += beta * (getColor(biased) * sum_lights intensity)
+      RGBA color = getColor(S, prim, biased);
+      B.shPoint[slot] = make_float4(biased.x, biased.y, biased.z, 0);
+      B.shNormal[slot] = make_float4(normal.x, normal.y, normal.z, 0);
+      B.shColor[slot] = f4(color);
+      B.shWeight[slot] = f4(beta);
+      // Environment lights draw their hemisphere direction here, in light order, before the BSDF draws (Object.cpp:42)
+      for (int k = 0; k < S.numLights; ++k) {
+        if (S.lights[k].type == RT_LIGHT_ENVIRONMENT) {
+          V3 wi = sampleHemisphere(normal, rng);
+          B.envWi[(int64_t)S.lights[k].envSlot * B.P + slot] = make_float4(wi.x, wi.y, wi.z, 0);
+        }
+      }
+      const DevMaterial &mat = S.materials[matIdx];
+      if (mat.type == RT_MAT_METAL) mulAssign(beta, objColor);  // raytracer.cpp:233-234
+      if (bounce + 1 < S.maxBounces) {
+        // The reference samples the BSDF on the last bounce too but never uses the result.
+        float pdf = 0.0f;
+        V3 wi;
+        float contribution = bsdfSample(mat, wo, wi, normal, rng, pdf);
+        if (!(pdf == 0 || contribution == 0)) {
+          continues = true;
+          mulAssign(beta, contribution * fabsf(dot(wi, normal)) / pdf);
+          bool exiting = dot(wi, outNormal) > 0;
+          V3 no = point + outNormal * (exiting ? S.bias : -S.bias);
+          B.rayO[slot] = make_float4(no.x, no.y, no.z, 0);
+          B.rayD[slot] = make_float4(wi.x, wi.y, wi.z, 0);
+        }
+      }
+      B.beta[slot] = f4(beta);
+      B.rng[slot] = rng;
+    }
+  }
+  uint32_t qh = queueSlot(&B.counts->nHit, isHit);
+  if (isHit) B.qHit[qh] = slot;
+  uint32_t qn = queueSlot(&B.counts->nNext, continues);
+  if (continues) queueNext[qn] = slot;
+}
+
+// ---------------------------------------------------------------------------------------------------- k_shadow
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_shadow(DevScene S, PathBuf B) {
+  __shared__ uint2 ldsStack[kStackLds * kBlock];
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  TravCounters tc = {0, 0, 0};
+  bool overflow = false;
+  if (i < B.counts->nHit) {
+    uint32_t slot = B.qHit[i];
+    float4 p4 = B.shPoint[slot], n4 = B.shNormal[slot];
+    V3 point = v3(p4.x, p4.y, p4.z), n = v3(n4.x, n4.y, n4.z);
+    RGBA Lsum = rgba(0, 0, 0, 1);  // `RGBAColor L;` in Scene::illuminate, raytracer.cpp:199
+    for (int k = 0; k < S.numLights; ++k) {
+      const DevLight &l = S.lights[k];
+      RGBA lc = rgba(l.color[0], l.color[1], l.color[2], l.color[3]);
+      RGBA contrib = rgba(0, 0, 0, 1);
+      if (l.type == RT_LIGHT_DISTANT) {  // Object.cpp:7-16
+        V3 dir = v3(l.v);
+        HitRec h = traverse<true, COUNT, kStackLds, kBlock>(S, point, dir, ldsStack, tc, overflow);
+        if (h.prim < 0) contrib = lc * clipDot(n, dir);
+      } else if (l.type == RT_LIGHT_POINT) {  // Object.cpp:18-34
+        V3 lightDirection = v3(l.v) - point;
+        float intersectToBulbDist = magnitude(lightDirection);
+        HitRec h = traverse<false, COUNT, kStackLds, kBlock>(S, point, lightDirection, ldsStack, tc, overflow);
+        bool shadowed = false;
+        if (h.prim >= 0) {
+          V3 hp = h.t * normalized(lightDirection) + point;
+          shadowed = magnitude(point - hp) < intersectToBulbDist;
+        }
+        if (!shadowed) {
+          float distance = magnitude(lightDirection);
+          float invDistance = 1.0f / (distance * distance);
+          contrib = lc * clipDot(n, lightDirection) * invDistance;
+        }
+      } else {  // environment, Object.cpp:36-46
+        float4 w4 = B.envWi[(int64_t)l.envSlot * B.P + slot];
+        V3 wi = v3(w4.x, w4.y, w4.z);
+        HitRec h = traverse<true, COUNT, kStackLds, kBlock>(S, point, wi, ldsStack, tc, overflow);
+        if (h.prim < 0) contrib = emittedLight(S, l, wi) * clipDot(n, wi);
+      }
+      addAssign(Lsum, contrib);
+    }
+    RGBA L = rgba(B.L[slot]);
+    addAssign(L, rgba(B.shWeight[slot]) * (rgba(B.shColor[slot]) * Lsum));  // raytracer.cpp:205, 231
+    B.L[slot] = f4(L);
+  }
+  flushCounters<COUNT>(B.counts, tc, overflow, 1);
+}
+
+// ---------------------------------------------------------------------------------------------------- bookkeeping
+__global__ void k_advance(PathBuf B, int32_t numPointLights, int32_t numAnyLights) {
+  Counts *c = B.counts;
+  c->raysClosest += (unsigned long long)c->nActive + (unsigned long long)c->nHit * numPointLights;
+  c->raysAny += (unsigned long long)c->nHit * numAnyLights;
+  c->raysExtend += c->nActive;
+  c->raysShadow += (unsigned long long)c->nHit * (numPointLights + numAnyLights);
+  c->nActive = c->nNext;
+  c->nNext = 0;
+  c->nHit = 0;
+}
+__global__ void k_begin_pass(PathBuf B) {
+  Counts *c = B.counts;
+  c->nActive = 0; c->nNext = 0; c->nHit = 0;
+}
+__global__ void k_count_samples(PathBuf B) { B.counts->samples += B.counts->nActive; }
+
+// Per pixel: fold this pass's samples, in sample order, into the running sum (raytracer.cpp:48-51).
+__global__ __launch_bounds__(kBlock) void k_accumulate(PathBuf B, float4 *pixSum, int32_t *pixHits, int32_t sppThis) {
+  int32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= B.npix) return;
+  RGBA avg = rgba(pixSum[p]);
+  int hits = pixHits[p];
+  for (int s = 0; s < sppThis; ++s) {
+    RGBA color = rgba(B.L[(int64_t)s * B.npix + p]);
+    if (hasNaN(color) == false && color.a != 0) {
+      addAssign(avg, color);
+      ++hits;
+    }
+  }
+  pixSum[p] = f4(avg);
+  pixHits[p] = hits;
+}
+
+// raytracer.cpp:54-59 then Scene::expose (:303-312)
+__global__ __launch_bounds__(kBlock) void k_resolve(DevScene S, int32_t npix, const int32_t *pixList, const float4 *pixSum,
+                                                    const int32_t *pixHits, float4 *fb, int32_t applyExposure) {
+  int32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= npix) return;
+  RGBA avg = rgba(pixSum[p]);
+  int hits = pixHits[p];
+  float invNumRays = (float)(1.0 / (double)S.numRays);
+  if (hits != 0) {
+    mulAssign(avg, 1.0f / hits);
+    avg.a = hits * invNumRays;
+  }
+  // clipColor, src/image/PNG.cpp:99-106
+  RGBA c = rgba(rmax(0.0f, rmin(avg.r, 1.0f)), rmax(0.0f, rmin(avg.g, 1.0f)), rmax(0.0f, rmin(avg.b, 1.0f)),
+                rmax(0.0f, rmin(avg.a, 1.0f)));
+  if (applyExposure) {  // exponentialExposure, src/image/PNG.cpp:20-22 (float exp, double subtraction)
+    c.r = (float)(1.0 - (double)expf(-1 * c.r * S.exposure));
+    c.g = (float)(1.0 - (double)expf(-1 * c.g * S.exposure));
+    c.b = (float)(1.0 - (double)expf(-1 * c.b * S.exposure));
+  }
+  fb[pixList[p]] = f4(c);
+}
+
+// PNG::saveToFile's conversion, src/image/PNG.cpp:7-12, 149-157
+RT_DEV float linearToGamma(float channel) {
+  if ((double)channel < 0.0031308) return (float)(12.92 * (double)channel);
+  return (float)(1.055 * pow((double)channel, 1 / 2.4) - 0.055);
+}
+__global__ __launch_bounds__(kBlock) void k_srgb8(const float4 *fb, uchar4 *out, int32_t n) {
+  int32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  float4 c = fb[i];
+  uchar4 o;
+  o.x = (unsigned char)roundf(linearToGamma(c.x) * 255);
+  o.y = (unsigned char)roundf(linearToGamma(c.y) * 255);
+  o.z = (unsigned char)roundf(linearToGamma(c.z) * 255);
+  o.w = (unsigned char)roundf(c.w * 255);
+  out[i] = o;
+}
+
+// ---------------------------------------------------------------------------------------------------- trace-only kernels
+RT_DEV int32_t reportedId(const DevScene &S, int32_t prim) {
+  return prim < 0 ? -1 : (prim < S.numPrims ? S.primOrigIndex[prim] : prim);
+}
+
+__global__ __launch_bounds__(kBlock) void k_trace_primary(DevScene S, int32_t x0, int32_t y0, int32_t w, int32_t h,
+                                                          int32_t *outPrim, float *outT, Counts *counts) {
+  __shared__ uint2 ldsStack[kStackLds * kBlock];
+  // 8x8 pixel tiles per wavefront: neighbouring lanes walk the same part of the tree
+  int32_t tilesX = (w + 7) / 8;
+  int32_t wave = (blockIdx.x * kBlock + threadIdx.x) / 64, lane = threadIdx.x & 63;
+  int32_t col = (wave % tilesX) * 8 + (lane & 7), row = (wave / tilesX) * 8 + (lane >> 3);
+  TravCounters tc = {0, 0, 0};
+  bool overflow = false;
+  if (col < w && row < h) {
+    int32_t x = x0 + col, y = y0 + row;
+    float Sx = getRayScaleX((float)x, S.width, S.height);
+    float Sy = getRayScaleY((float)y, S.width, S.height);
+    V3 d = v3(S.forward) + Sx * v3(S.right) + Sy * v3(S.up);
+    HitRec hr = traverse<false, false, kStackLds, kBlock>(S, v3(S.eye), d, ldsStack, tc, overflow);
+    int64_t j = (int64_t)row * w + col;
+    outPrim[j] = reportedId(S, hr.prim);
+    outT[j] = hr.t;
+  }
+  flushCounters<false>(counts, tc, overflow, 0);
+}
+
+template <bool ANY>
+__global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene S, int64_t n, const float *origins, const float *directions,
+                                                       int32_t *outPrim, float *outT, float *outPoint, float *outNormal,
+                                                       uint8_t *outOccluded, Counts *counts) {
+  __shared__ uint2 ldsStack[kStackLds * kBlock];
+  int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  TravCounters tc = {0, 0, 0};
+  bool overflow = false;
+  if (j < n) {
+    V3 o = v3(origins + 3 * j), d = v3(directions + 3 * j);
+    HitRec hr = traverse<ANY, false, kStackLds, kBlock>(S, o, d, ldsStack, tc, overflow);
+    if (ANY) {
+      outOccluded[j] = hr.prim >= 0 ? 1 : 0;
+    } else {
+      if (outPrim) outPrim[j] = reportedId(S, hr.prim);
+      if (outT) outT[j] = hr.t;
+      V3 point = v3(0, 0, 0), normal = v3(0, 0, 0);
+      if (hr.prim >= 0 && (outPoint || outNormal)) {
+        V3 nd = normalized(d);
+        point = hr.t * nd + o;
+        if (hr.prim >= S.numPrims) {
+          normal = v3(S.planes[hr.prim - S.numPrims].normal);
+        } else {
+          const float4 *P = S.primHit + 3 * (int64_t)hr.prim;
+          float4 a = P[0], b = P[1], c = P[2];
+          if ((__float_as_uint(a.w) | __float_as_uint(b.x) | __float_as_uint(b.y)) == 0u) {
+            normal = normalized(point - v3(a.x, a.y, a.z));
+          } else {
+            V3 p1 = v3(a.x, a.y, a.z), e1 = v3(b.z, b.w, c.x), e2 = v3(c.y, c.z, c.w);
+            V3 q = point - p1;
+            float b2 = dot(e1, q), b3 = dot(e2, q);
+            float b1 = 1.0f - b3 - b2;
+            const float *nn = S.primNormals + 9 * (int64_t)hr.prim;
+            normal = normalized(v3(nn) * b1 + v3(nn + 3) * b2 + v3(nn + 6) * b3);
+          }
+        }
+      }
+      if (outPoint) { outPoint[3 * j] = point.x; outPoint[3 * j + 1] = point.y; outPoint[3 * j + 2] = point.z; }
+      if (outNormal) { outNormal[3 * j] = normal.x; outNormal[3 * j + 1] = normal.y; outNormal[3 * j + 2] = normal.z; }
+    }
+  }
+  flushCounters<false>(counts, tc, overflow, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------- host side
+thread_local std::string g_error;
+
+int failMsg(int code, const std::string &msg) { g_error = msg; return code; }
+
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) {                                                                             \
+      g_error = std::string(#expr) + ": " + hipGetErrorString(e_);                                      \
+      return RT_ERR_DEVICE;                                                                             \
+    }                                                                                                   \
+  } while (0)
+
+struct EventPair {
+  hipEvent_t a, b;
+  int category;
+};
+enum { CAT_RAYGEN, CAT_EXTEND, CAT_SHADE, CAT_SHADOW, CAT_ACCUM, CAT_RESOLVE, CAT_TOTAL, CAT_COUNT };
+
+}  // namespace
+
+struct RtScene {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevScene dev{};
+  std::vector<void *> allocs;
+  int32_t numPointLights = 0, numAnyLights = 0, numEnvLights = 0;
+  // render state (allocated on first use, grown when needed)
+  PathBuf buf{};
+  void *arena = nullptr;
+  size_t arenaBytes = 0;
+  int64_t arenaP = 0;
+  int32_t *pixList = nullptr;
+  float4 *pixSum = nullptr;
+  int32_t *pixHits = nullptr;
+  float4 *fb = nullptr;
+  int64_t fbPixels = 0, pixCap = 0;
+  Counts *counts = nullptr;
+  std::vector<EventPair> events;
+  size_t eventsUsed = 0;
+};
+
+namespace {
+
+template <typename T>
+int upload(RtScene *s, const T *host, size_t n, const T **dev) {
+  *dev = nullptr;
+  if (n == 0) return RT_OK;
+  void *p = nullptr;
+  HIP_TRY(hipMalloc(&p, n * sizeof(T)));
+  s->allocs.push_back(p);
+  HIP_TRY(hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+  *dev = static_cast<const T *>(p);
+  return RT_OK;
+}
+
+// Material -> lobes, src/scene/Material.cpp:4-36 with the constants of src/bsdf/BDF.h:108-115 and
+// src/bsdf/microfacets.cpp:49-51 evaluated on the host exactly as the constructors do.
+bool makeMaterial(const RtMaterial &m, DevMaterial &out) {
+  std::memset(&out, 0, sizeof out);
+  out.type = m.type;
+  auto microfacet = [&](int fresnel, float fI, float fT, float fK) {
+    DevLobe l{};
+    l.kind = LOBE_MICROFACET; l.Kr = m.Kr;
+    l.alpha = std::sqrt(std::min(1e-4f, m.roughness));
+    l.fresnel = fresnel; l.fEtaI = fI; l.fEtaT = fT; l.fK = fK;
+    return l;
+  };
+  switch (m.type) {
+    case RT_MAT_DEFAULT: {
+      DevLobe l{}; l.kind = LOBE_LAMBERT; l.Kr = 1.0f;
+      out.lobes[0] = l; out.numLobes = 1;
+      return true;
+    }
+    case RT_MAT_METAL:
+      out.lobes[0] = microfacet(FRESNEL_CONDUCTOR, 1.0f, m.eta, m.Ka); out.numLobes = 1;
+      return true;
+    case RT_MAT_MIRROR: {
+      DevLobe l{}; l.kind = LOBE_SPECULAR_REFLECTION; l.Kr = m.Kr; l.fresnel = FRESNEL_DIELECTRIC; l.fEtaI = 1.0f; l.fEtaT = m.eta;
+      out.lobes[0] = l; out.numLobes = 1;
+      return true;
+    }
+    case RT_MAT_PLASTIC: {
+      DevLobe o{}; o.kind = LOBE_OREN_NAYAR; o.Kr = m.Kd;
+      float sigma = 20;
+      sigma *= M_PI / 180;
+      float sigma2 = sigma * sigma;
+      o.A = 1.0f - 0.5 * sigma2 / (sigma2 + 0.33);
+      o.B = 0.45 * sigma2 / (sigma2 + 0.09);
+      out.lobes[0] = o;
+      out.lobes[1] = microfacet(FRESNEL_DIELECTRIC, 1.0f, m.eta, 0.0f);
+      out.numLobes = 2;
+      return true;
+    }
+    case RT_MAT_GLASS: {
+      DevLobe l{}; l.kind = LOBE_FRESNEL_SPECULAR; l.Kr = m.Kr; l.Kt = m.Kt; l.etaI = 1.0f; l.etaT = m.eta;
+      out.lobes[0] = l; out.numLobes = 1;
+      return true;
+    }
+    default: return false;
+  }
+}
+
+void setView(RtScene *s, const RtCamera &cam, const RtOptions &o) {
+  DevScene &d = s->dev;
+  std::memcpy(d.eye, cam.eye, 12); std::memcpy(d.forward, cam.forward, 12);
+  std::memcpy(d.right, cam.right, 12); std::memcpy(d.up, cam.up, 12);
+  d.width = o.width; d.height = o.height; d.bias = o.bias; d.exposure = o.exposure;
+  d.maxBounces = o.maxBounces; d.numRays = o.numRays; d.focus = o.focus; d.lens = o.lens;
+  d.cameraMode = o.fisheye ? 1 : (o.focus > 0 ? 2 : 0);  // src/scene/raytracer.cpp:290-299
+  auto mag = [](const float *v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+  float fl = mag(cam.forward);
+  d.invForwardLength = (float)(1.0 / (double)fl);  // raytracer.cpp:75
+  float inv = 1.0f / fl;
+  d.normalizedForward[0] = cam.forward[0] * inv; d.normalizedForward[1] = cam.forward[1] * inv; d.normalizedForward[2] = cam.forward[2] * inv;
+  d.magRight = mag(cam.right); d.magUp = mag(cam.up);
+}
+
+int validateDesc(const RtSceneDesc *d) {
+  if (!d) return failMsg(RT_ERR_INVALID, "null scene description");
+  if (d->numPrims < 0 || d->numNodes < 0 || d->numPlanes < 0 || d->numLights < 0 || d->numMaterials < 0 || d->numTextures < 0)
+    return failMsg(RT_ERR_INVALID, "negative count in scene description");
+  if (d->numPrims > 0 && (!d->nodes || d->numNodes <= 0 || !d->primKind || !d->primHit || !d->primNormals || !d->primColor ||
+                          !d->primMaterial || !d->primTexture || !d->primOrigIndex))
+    return failMsg(RT_ERR_INVALID, "missing array in scene description");
+  if (d->numPrims == 0 && d->numNodes != 0) return failMsg(RT_ERR_INVALID, "BVH nodes without objects");
+  // The kernels index with these values: check every one on the host, before anything reaches the GPU.
+  for (int32_t i = 0; i < d->numNodes; ++i) {
+    const RtBvhNode &n = d->nodes[i];
+    if (n.numObjects > 0) {
+      if (n.rightOrStart < 0 || (int64_t)n.rightOrStart + n.numObjects > d->numPrims)
+        return failMsg(RT_ERR_INVALID, "BVH leaf " + std::to_string(i) + " points outside the object array");
+    } else {
+      if (i + 1 >= d->numNodes || n.rightOrStart <= i + 1 || n.rightOrStart >= d->numNodes)
+        return failMsg(RT_ERR_INVALID, "BVH inner node " + std::to_string(i) + " has a child outside the node array");
+    }
+  }
+  bool texturedTriangle = false;
+  for (int32_t i = 0; i < d->numPrims; ++i) {
+    if (d->primKind[i] != RT_PRIM_TRIANGLE && d->primKind[i] != RT_PRIM_SPHERE) return failMsg(RT_ERR_INVALID, "bad primKind");
+    if (d->primMaterial[i] < 0 || d->primMaterial[i] >= d->numMaterials) return failMsg(RT_ERR_INVALID, "object material index out of range");
+    if (d->primTexture[i] >= d->numTextures) return failMsg(RT_ERR_INVALID, "object texture index out of range");
+    texturedTriangle |= d->primKind[i] == RT_PRIM_TRIANGLE && d->primTexture[i] >= 0;
+  }
+  if (texturedTriangle && !d->primTexCoords) return failMsg(RT_ERR_INVALID, "textured triangles need primTexCoords");
+  for (int32_t i = 0; i < d->numPlanes; ++i) {
+    if (d->planes[i].material < 0 || d->planes[i].material >= d->numMaterials) return failMsg(RT_ERR_INVALID, "plane material index out of range");
+    if (d->planes[i].texture >= d->numTextures) return failMsg(RT_ERR_INVALID, "plane texture index out of range");
+  }
+  for (int32_t i = 0; i < d->numLights; ++i) {
+    if (d->lights[i].type < RT_LIGHT_DISTANT || d->lights[i].type > RT_LIGHT_ENVIRONMENT) return failMsg(RT_ERR_INVALID, "bad light type");
+    if (d->lights[i].texture >= d->numTextures) return failMsg(RT_ERR_INVALID, "light texture index out of range");
+  }
+  for (int32_t i = 0; i < d->numTextures; ++i)
+    if (d->textures[i].width < 0 || d->textures[i].height < 0 || (d->textures[i].width > 0 && d->textures[i].height > 0 && !d->textures[i].rgba))
+      return failMsg(RT_ERR_INVALID, "bad texture");
+  if (d->options.width <= 0 || d->options.height <= 0) return failMsg(RT_ERR_INVALID, "bad image size");
+  return RT_OK;
+}
+
+int buildScene(RtScene *s, const RtSceneDesc *d) {
+  DevScene &dev = s->dev;
+  // ---- BVH: pre-order 32-byte nodes -> one 64-byte record per inner node
+  std::vector<int32_t> innerOrdinal(d->numNodes, -1);
+  int32_t numInner = 0;
+  for (int32_t i = 0; i < d->numNodes; ++i)
+    if (d->nodes[i].numObjects <= 0) innerOrdinal[i] = numInner++;
+  std::vector<BigLeaf> bigLeaves;
+  auto childRef = [&](int32_t node) -> int32_t {
+    const RtBvhNode &n = d->nodes[node];
+    if (n.numObjects <= 0) return innerOrdinal[node];
+    if (n.numObjects < 128 && n.rightOrStart < (1 << 24)) return (int32_t)(0x80000000u | ((uint32_t)n.numObjects << 24) | (uint32_t)n.rightOrStart);
+    bigLeaves.push_back({n.rightOrStart, n.numObjects});
+    return (int32_t)(0x80000000u | (uint32_t)(bigLeaves.size() - 1));
+  };
+  std::vector<float4> nodes((size_t)numInner * 4);
+  for (int32_t i = 0; i < d->numNodes; ++i) {
+    if (innerOrdinal[i] < 0) continue;
+    const RtBvhNode &l = d->nodes[i + 1];
+    const RtBvhNode &r = d->nodes[d->nodes[i].rightOrStart];
+    float4 *N = &nodes[(size_t)innerOrdinal[i] * 4];
+    N[0] = make_float4(l.aabbMin[0], l.aabbMin[1], l.aabbMin[2], l.aabbMax[0]);
+    N[1] = make_float4(l.aabbMax[1], l.aabbMax[2], r.aabbMin[0], r.aabbMin[1]);
+    N[2] = make_float4(r.aabbMin[2], r.aabbMax[0], r.aabbMax[1], r.aabbMax[2]);
+    int32_t refs[4] = {childRef(i + 1), childRef(d->nodes[i].rightOrStart), 0, 0};
+    std::memcpy(&N[3], refs, 16);
+  }
+  if (bigLeaves.size() >= (1u << 24)) return failMsg(RT_ERR_INVALID, "too many oversized BVH leaves");
+  if (d->numNodes > 0) {
+    dev.rootRef = childRef(0);
+    std::memcpy(dev.rootMin, d->nodes[0].aabbMin, 12);
+    std::memcpy(dev.rootMax, d->nodes[0].aabbMax, 12);
+  } else {
+    dev.rootRef = kNoBvh;
+  }
+  if (bigLeaves.empty()) bigLeaves.push_back({0, 0});
+  // ---- objects
+  size_t n = (size_t)d->numPrims;
+  std::vector<float4> primHit(n * 3);
+  int hasSpheres = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const float *h = d->primHit + i * 12;
+    if (d->primKind[i] == RT_PRIM_SPHERE) {
+      hasSpheres = 1;
+      primHit[i * 3 + 0] = make_float4(h[0], h[1], h[2], 0.0f);
+      primHit[i * 3 + 1] = make_float4(0.0f, 0.0f, h[3], 0.0f);
+      primHit[i * 3 + 2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    } else {
+      primHit[i * 3 + 0] = make_float4(h[0], h[1], h[2], h[3]);
+      primHit[i * 3 + 1] = make_float4(h[4], h[5], h[6], h[7]);
+      primHit[i * 3 + 2] = make_float4(h[8], h[9], h[10], h[11]);
+      uint32_t nb[3];
+      std::memcpy(nb, h + 3, 12);
+      if ((nb[0] | nb[1] | nb[2]) == 0u) return failMsg(RT_ERR_INVALID, "triangle with an all-zero normal");
+    }
+  }
+  dev.numPrims = d->numPrims;
+  dev.hasSpheres = hasSpheres;
+  int rc;
+  if ((rc = upload(s, nodes.data(), nodes.size(), &dev.nodes))) return rc;
+  if ((rc = upload(s, primHit.data(), primHit.size(), &dev.primHit))) return rc;
+  if ((rc = upload(s, bigLeaves.data(), bigLeaves.size(), &dev.bigLeaves))) return rc;
+  if ((rc = upload(s, d->primNormals, n * 9, &dev.primNormals))) return rc;
+  if (d->primTexCoords) { if ((rc = upload(s, d->primTexCoords, n * 9, &dev.primTexCoords))) return rc; }
+  if ((rc = upload(s, reinterpret_cast<const float4 *>(d->primColor), n, &dev.primColor))) return rc;
+  if ((rc = upload(s, d->primMaterial, n, &dev.primMaterial))) return rc;
+  if ((rc = upload(s, d->primTexture, n, &dev.primTexture))) return rc;
+  if ((rc = upload(s, d->primOrigIndex, n, &dev.primOrigIndex))) return rc;
+  // ---- planes, materials, lights, textures
+  std::vector<DevPlane> planes(d->numPlanes);
+  for (int32_t i = 0; i < d->numPlanes; ++i) {
+    const RtPlane &p = d->planes[i];
+    DevPlane q{};
+    std::memcpy(q.normal, p.normal, 12); std::memcpy(q.point, p.point, 12);
+    std::memcpy(q.texTopLeft, p.texTopLeft, 12); q.texZoom = p.texZoom; std::memcpy(q.texShift, p.texShift, 12);
+    std::memcpy(q.color, p.color, 16); q.material = p.material; q.texture = p.texture;
+    planes[i] = q;
+  }
+  dev.numPlanes = d->numPlanes;
+  if ((rc = upload(s, planes.data(), planes.size(), &dev.planes))) return rc;
+  std::vector<DevMaterial> mats(d->numMaterials);
+  std::vector<bool> used(d->numMaterials, false);
+  for (size_t i = 0; i < n; ++i) used[d->primMaterial[i]] = true;
+  for (int32_t i = 0; i < d->numPlanes; ++i) used[d->planes[i].material] = true;
+  for (int32_t i = 0; i < d->numMaterials; ++i)
+    if (!makeMaterial(d->materials[i], mats[i]) && used[i]) return failMsg(RT_ERR_INVALID, "material " + std::to_string(i) + " has an unsupported type");
+  if ((rc = upload(s, mats.data(), mats.size(), &dev.materials))) return rc;
+  std::vector<DevLight> lights(d->numLights);
+  for (int32_t i = 0; i < d->numLights; ++i) {
+    const RtLight &l = d->lights[i];
+    DevLight q{};
+    q.type = l.type; std::memcpy(q.color, l.color, 16); std::memcpy(q.v, l.v, 12); q.radius = l.radius; q.texture = l.texture;
+    q.envSlot = -1;
+    if (l.type == RT_LIGHT_ENVIRONMENT) { q.envSlot = s->numEnvLights++; s->numAnyLights++; }
+    else if (l.type == RT_LIGHT_DISTANT) s->numAnyLights++;
+    else s->numPointLights++;
+    lights[i] = q;
+  }
+  dev.numLights = d->numLights; dev.numEnvLights = s->numEnvLights; dev.numPointLights = s->numPointLights; dev.numAnyLights = s->numAnyLights;
+  if ((rc = upload(s, lights.data(), lights.size(), &dev.lights))) return rc;
+  std::vector<DevTexture> texs(d->numTextures);
+  size_t totalTexels = 0;
+  for (int32_t i = 0; i < d->numTextures; ++i) {
+    texs[i].width = d->textures[i].width; texs[i].height = d->textures[i].height; texs[i].offset = (int64_t)totalTexels;
+    totalTexels += (size_t)d->textures[i].width * d->textures[i].height;
+  }
+  std::vector<float4> texels(totalTexels);
+  for (int32_t i = 0; i < d->numTextures; ++i) {
+    size_t cnt = (size_t)d->textures[i].width * d->textures[i].height;
+    if (cnt) std::memcpy(&texels[texs[i].offset], d->textures[i].rgba, cnt * 16);
+  }
+  if ((rc = upload(s, texs.data(), texs.size(), &dev.textures))) return rc;
+  if ((rc = upload(s, texels.data(), texels.size(), &dev.texels))) return rc;
+  setView(s, d->camera, d->options);
+  void *c = nullptr;
+  HIP_TRY(hipMalloc(&c, sizeof(Counts)));
+  s->allocs.push_back(c);
+  s->counts = static_cast<Counts *>(c);
+  HIP_TRY(hipMemset(c, 0, sizeof(Counts)));
+  return RT_OK;
+}
+
+bool inPartition(const RtRenderParams &p, int tilesX, int tw, int th, int x, int y) {
+  if (p.partCount <= 1) return true;
+  int tile = (y / th) * tilesX + (x / tw);
+  return tile % p.partCount == p.partIndex;
+}
+
+// Pixels of this call's partition, ordered so that 64 consecutive entries are an 8x8 block wherever possible.
+std::vector<int32_t> buildPixelList(const RtRenderParams &p, int W, int H) {
+  int tw = p.tileW > 0 ? p.tileW : 32, th = p.tileH > 0 ? p.tileH : 32;
+  int tilesX = (W + tw - 1) / tw;
+  std::vector<int32_t> list;
+  list.reserve((size_t)W * H / std::max(1, p.partCount) + 64);
+  for (int by = 0; by < H; by += 8)
+    for (int bx = 0; bx < W; bx += 8)
+      for (int y = by; y < std::min(by + 8, H); ++y)
+        for (int x = bx; x < std::min(bx + 8, W); ++x)
+          if (inPartition(p, tilesX, tw, th, x, y)) list.push_back(y * W + x);
+  return list;
+}
+
+int ensureRenderBuffers(RtScene *s, int64_t P, int64_t npix, int64_t fbPixels) {
+  if (s->fbPixels < fbPixels) {
+    if (s->fb) (void)hipFree(s->fb);
+    s->fb = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->fb), fbPixels * sizeof(float4)));
+    s->fbPixels = fbPixels;
+  }
+  if (s->pixCap < npix) {
+    if (s->pixList) (void)hipFree(s->pixList);
+    if (s->pixSum) (void)hipFree(s->pixSum);
+    if (s->pixHits) (void)hipFree(s->pixHits);
+    s->pixList = nullptr; s->pixSum = nullptr; s->pixHits = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->pixList), npix * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->pixSum), npix * sizeof(float4)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->pixHits), npix * sizeof(int32_t)));
+    s->pixCap = npix;
+  }
+  if (s->arenaP < P) {
+    if (s->arena) (void)hipFree(s->arena);
+    s->arena = nullptr;
+    int64_t nEnv = std::max(1, s->numEnvLights);
+    size_t bytes = (size_t)P * (sizeof(float4) * (8 + nEnv) + 4 * 6) + 4096;
+    HIP_TRY(hipMalloc(&s->arena, bytes));
+    s->arenaBytes = bytes;
+    s->arenaP = P;
+  }
+  // carve with the capacity the arena was allocated for, so the layout is the same for calls with a smaller P
+  int64_t cap = s->arenaP;
+  PathBuf &b = s->buf;
+  size_t f4b = (size_t)cap * sizeof(float4);
+  char *base = static_cast<char *>(s->arena);
+  b.rayO = reinterpret_cast<float4 *>(base); base += f4b;
+  b.rayD = reinterpret_cast<float4 *>(base); base += f4b;
+  b.beta = reinterpret_cast<float4 *>(base); base += f4b;
+  b.L = reinterpret_cast<float4 *>(base); base += f4b;
+  b.shPoint = reinterpret_cast<float4 *>(base); base += f4b;
+  b.shNormal = reinterpret_cast<float4 *>(base); base += f4b;
+  b.shColor = reinterpret_cast<float4 *>(base); base += f4b;
+  b.shWeight = reinterpret_cast<float4 *>(base); base += f4b;
+  b.envWi = reinterpret_cast<float4 *>(base); base += f4b * std::max(1, s->numEnvLights);
+  b.rng = reinterpret_cast<uint32_t *>(base); base += (size_t)cap * 4;
+  b.hitT = reinterpret_cast<float *>(base); base += (size_t)cap * 4;
+  b.hitPrim = reinterpret_cast<int32_t *>(base); base += (size_t)cap * 4;
+  b.qA = reinterpret_cast<uint32_t *>(base); base += (size_t)cap * 4;
+  b.qB = reinterpret_cast<uint32_t *>(base); base += (size_t)cap * 4;
+  b.qHit = reinterpret_cast<uint32_t *>(base); base += (size_t)cap * 4;
+  b.counts = s->counts;
+  b.P = (int32_t)P;
+  b.npix = (int32_t)npix;
+  return RT_OK;
+}
+
+int beginEvent(RtScene *s, int category, bool enabled) {
+  if (!enabled) return RT_OK;
+  if (s->eventsUsed == s->events.size()) {
+    EventPair e{};
+    HIP_TRY(hipEventCreate(&e.a));
+    HIP_TRY(hipEventCreate(&e.b));
+    s->events.push_back(e);
+  }
+  s->events[s->eventsUsed].category = category;
+  HIP_TRY(hipEventRecord(s->events[s->eventsUsed].a, s->stream));
+  return RT_OK;
+}
+int endEvent(RtScene *s, bool enabled) {
+  if (!enabled) return RT_OK;
+  HIP_TRY(hipEventRecord(s->events[s->eventsUsed].b, s->stream));
+  ++s->eventsUsed;
+  return RT_OK;
+}
+
+inline unsigned gridFor(int64_t n) { return (unsigned)std::max<int64_t>(1, (n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_error.c_str(); }
+const char *rt_version(void) { return "raytracer_amd 0.1 (gfx950 wavefront path tracer)"; }
+
+RtScene *rt_scene_create(const RtSceneDesc *desc, int device) {
+  if (validateDesc(desc) != RT_OK) return nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) { g_error = std::string("no HIP device available: ") + hipGetErrorString(e); return nullptr; }
+  if (device < 0 || device >= count) { g_error = "device index out of range"; return nullptr; }
+  if ((e = hipSetDevice(device)) != hipSuccess) { g_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return nullptr; }
+  auto s = std::make_unique<RtScene>();
+  s->device = device;
+  if ((e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)) != hipSuccess) {
+    g_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+    return nullptr;
+  }
+  if (buildScene(s.get(), desc) != RT_OK) {
+    RtScene *raw = s.release();
+    rt_scene_destroy(raw);
+    return nullptr;
+  }
+  return s.release();
+}
+
+void rt_scene_destroy(RtScene *s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  for (void *p : s->allocs) (void)hipFree(p);
+  if (s->arena) (void)hipFree(s->arena);
+  if (s->pixList) (void)hipFree(s->pixList);
+  if (s->pixSum) (void)hipFree(s->pixSum);
+  if (s->pixHits) (void)hipFree(s->pixHits);
+  if (s->fb) (void)hipFree(s->fb);
+  for (auto &e : s->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+int rt_scene_set_view(RtScene *s, const RtCamera *camera, const RtOptions *options) {
+  if (!s) return failMsg(RT_ERR_INVALID, "null scene");
+  RtCamera cam;
+  std::memcpy(cam.eye, s->dev.eye, 12); std::memcpy(cam.forward, s->dev.forward, 12);
+  std::memcpy(cam.right, s->dev.right, 12); std::memcpy(cam.up, s->dev.up, 12);
+  RtOptions o;
+  o.width = s->dev.width; o.height = s->dev.height; o.bias = s->dev.bias; o.exposure = s->dev.exposure;
+  o.maxBounces = s->dev.maxBounces; o.numRays = s->dev.numRays; o.fisheye = s->dev.cameraMode == 1;
+  o.focus = s->dev.focus; o.lens = s->dev.lens;
+  if (camera) cam = *camera;
+  if (options) {
+    if (options->width <= 0 || options->height <= 0) return failMsg(RT_ERR_INVALID, "bad image size");
+    o = *options;
+  }
+  setView(s, cam, o);
+  return RT_OK;
+}
+
+int rt_trace_primary(RtScene *s, int32_t x0, int32_t y0, int32_t w, int32_t h, int32_t *primId, float *t) {
+  if (!s || !primId || !t) return failMsg(RT_ERR_INVALID, "null argument");
+  if (w <= 0 || h <= 0) return failMsg(RT_ERR_INVALID, "empty rectangle");
+  HIP_TRY(hipSetDevice(s->device));
+  int64_t n = (int64_t)w * h;
+  int32_t *dPrim = nullptr;
+  float *dT = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dPrim), n * 4));
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dT), n * 4));
+  int64_t waves = (int64_t)((w + 7) / 8) * ((h + 7) / 8);
+  k_trace_primary<<<gridFor(waves * 64), kBlock, 0, s->stream>>>(s->dev, x0, y0, w, h, dPrim, dT, s->counts);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(primId, dPrim, n * 4, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(t, dT, n * 4, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  (void)hipFree(dPrim); (void)hipFree(dT);
+  if (e != hipSuccess) return failMsg(RT_ERR_DEVICE, std::string("rt_trace_primary: ") + hipGetErrorString(e));
+  return RT_OK;
+}
+
+static int traceRays(RtScene *s, bool any, int64_t n, const float *origins, const float *directions, int32_t *primId, float *t,
+                     float *point, float *normal, uint8_t *occluded) {
+  if (!s || !origins || !directions) return failMsg(RT_ERR_INVALID, "null argument");
+  if (n <= 0) return RT_OK;
+  HIP_TRY(hipSetDevice(s->device));
+  float *dO = nullptr, *dD = nullptr, *dT = nullptr, *dP = nullptr, *dN = nullptr;
+  int32_t *dPrim = nullptr;
+  uint8_t *dOcc = nullptr;
+  std::vector<void *> tmp;
+  auto alloc = [&](void **p, size_t bytes) { hipError_t e = hipMalloc(p, bytes); if (e == hipSuccess) tmp.push_back(*p); return e; };
+  hipError_t e = alloc(reinterpret_cast<void **>(&dO), n * 12);
+  if (e == hipSuccess) e = alloc(reinterpret_cast<void **>(&dD), n * 12);
+  if (any) {
+    if (e == hipSuccess) e = alloc(reinterpret_cast<void **>(&dOcc), n);
+  } else {
+    if (e == hipSuccess && primId) e = alloc(reinterpret_cast<void **>(&dPrim), n * 4);
+    if (e == hipSuccess && t) e = alloc(reinterpret_cast<void **>(&dT), n * 4);
+    if (e == hipSuccess && point) e = alloc(reinterpret_cast<void **>(&dP), n * 12);
+    if (e == hipSuccess && normal) e = alloc(reinterpret_cast<void **>(&dN), n * 12);
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(dO, origins, n * 12, hipMemcpyHostToDevice, s->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dD, directions, n * 12, hipMemcpyHostToDevice, s->stream);
+  if (e == hipSuccess) {
+    if (any) k_trace_rays<true><<<gridFor(n), kBlock, 0, s->stream>>>(s->dev, n, dO, dD, nullptr, nullptr, nullptr, nullptr, dOcc, s->counts);
+    else k_trace_rays<false><<<gridFor(n), kBlock, 0, s->stream>>>(s->dev, n, dO, dD, dPrim, dT, dP, dN, nullptr, s->counts);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess && dOcc) e = hipMemcpyAsync(occluded, dOcc, n, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess && dPrim) e = hipMemcpyAsync(primId, dPrim, n * 4, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess && dT) e = hipMemcpyAsync(t, dT, n * 4, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess && dP) e = hipMemcpyAsync(point, dP, n * 12, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess && dN) e = hipMemcpyAsync(normal, dN, n * 12, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  for (void *p : tmp) (void)hipFree(p);
+  if (e != hipSuccess) return failMsg(RT_ERR_DEVICE, std::string("rt_trace: ") + hipGetErrorString(e));
+  return RT_OK;
+}
+
+int rt_trace_closest(RtScene *s, int64_t n, const float *origins, const float *directions, int32_t *primId, float *t, float *point,
+                     float *normal) {
+  return traceRays(s, false, n, origins, directions, primId, t, point, normal, nullptr);
+}
+
+int rt_trace_any(RtScene *s, int64_t n, const float *origins, const float *directions, uint8_t *occluded) {
+  if (!occluded) return failMsg(RT_ERR_INVALID, "null argument");
+  return traceRays(s, true, n, origins, directions, nullptr, nullptr, nullptr, nullptr, occluded);
+}
+
+int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats *stats) {
+  if (!s || !params) return failMsg(RT_ERR_INVALID, "null argument");
+  if (params->rngMode != RT_RNG_COUNTER) return failMsg(RT_ERR_INVALID, "the HIP library only implements RT_RNG_COUNTER");
+  if (params->partCount > 1 && (params->partIndex < 0 || params->partIndex >= params->partCount))
+    return failMsg(RT_ERR_INVALID, "partIndex out of range");
+  HIP_TRY(hipSetDevice(s->device));
+  const DevScene &S = s->dev;
+  int W = S.width, H = S.height;
+  if (S.numRays <= 0) return failMsg(RT_ERR_INVALID, "numRays must be positive");
+  std::vector<int32_t> pix = buildPixelList(*params, W, H);
+  int64_t npix = (int64_t)pix.size();
+  int64_t fbPixels = (int64_t)W * H;
+  int sppPass = params->samplesPerPass;
+  if (sppPass <= 0) sppPass = (int)std::max<int64_t>(1, (int64_t)(1 << 23) / std::max<int64_t>(1, npix));
+  sppPass = std::min(sppPass, S.numRays);
+  int64_t P = std::max<int64_t>(1, npix * sppPass);
+  if (P >= ((int64_t)1 << 31)) return failMsg(RT_ERR_INVALID, "samplesPerPass too large for this image");
+  int rc = ensureRenderBuffers(s, P, std::max<int64_t>(1, npix), fbPixels);
+  if (rc) return rc;
+  PathBuf B = s->buf;
+  bool timing = stats != nullptr;
+  bool count = params->collectCounters != 0;
+  s->eventsUsed = 0;
+  hipStream_t st = s->stream;
+  HIP_TRY(hipMemsetAsync(s->counts, 0, sizeof(Counts), st));
+  HIP_TRY(hipMemsetAsync(s->fb, 0, fbPixels * sizeof(float4), st));
+  if (npix > 0) {
+    HIP_TRY(hipMemcpyAsync(s->pixList, pix.data(), npix * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(s->pixSum, 0, npix * sizeof(float4), st));
+    HIP_TRY(hipMemsetAsync(s->pixHits, 0, npix * sizeof(int32_t), st));
+  }
+  if ((rc = beginEvent(s, CAT_TOTAL, timing))) return rc;
+  size_t totalIdx = s->eventsUsed;
+  if (timing) ++s->eventsUsed;  // the total pair stays open until the end
+  uint32_t passes = 0, launchesExtend = 0, launchesShadow = 0;
+  for (int sBase = 0; npix > 0 && sBase < S.numRays; sBase += sppPass, ++passes) {
+    int sppThis = std::min(sppPass, S.numRays - sBase);
+    int64_t n = npix * sppThis;
+    unsigned grid = gridFor(n);
+    k_begin_pass<<<1, 1, 0, st>>>(B);
+    if ((rc = beginEvent(s, CAT_RAYGEN, timing))) return rc;
+    k_raygen<<<grid, kBlock, 0, st>>>(S, B, s->pixList, sBase, sppThis, params->seed);
+    k_count_samples<<<1, 1, 0, st>>>(B);
+    if ((rc = endEvent(s, timing))) return rc;
+    uint32_t *qCur = B.qA, *qNext = B.qB;
+    for (int bounce = 0; bounce < S.maxBounces; ++bounce) {
+      if ((rc = beginEvent(s, CAT_EXTEND, timing))) return rc;
+      if (count) k_extend<true><<<grid, kBlock, 0, st>>>(S, B, qCur);
+      else k_extend<false><<<grid, kBlock, 0, st>>>(S, B, qCur);
+      if ((rc = endEvent(s, timing))) return rc;
+      ++launchesExtend;
+      if ((rc = beginEvent(s, CAT_SHADE, timing))) return rc;
+      k_shade<<<grid, kBlock, 0, st>>>(S, B, qCur, qNext, bounce);
+      if ((rc = endEvent(s, timing))) return rc;
+      if (S.numLights > 0) {
+        if ((rc = beginEvent(s, CAT_SHADOW, timing))) return rc;
+        if (count) k_shadow<true><<<grid, kBlock, 0, st>>>(S, B);
+        else k_shadow<false><<<grid, kBlock, 0, st>>>(S, B);
+        if ((rc = endEvent(s, timing))) return rc;
+        ++launchesShadow;
+      }
+      k_advance<<<1, 1, 0, st>>>(B, s->numPointLights, s->numAnyLights);
+      std::swap(qCur, qNext);
+    }
+    if ((rc = beginEvent(s, CAT_ACCUM, timing))) return rc;
+    k_accumulate<<<gridFor(npix), kBlock, 0, st>>>(B, s->pixSum, s->pixHits, sppThis);
+    if ((rc = endEvent(s, timing))) return rc;
+  }
+  if (npix > 0) {
+    if ((rc = beginEvent(s, CAT_RESOLVE, timing))) return rc;
+    int applyExposure = (S.exposure >= 0 && !params->skipExposure) ? 1 : 0;
+    k_resolve<<<gridFor(npix), kBlock, 0, st>>>(S, (int32_t)npix, s->pixList, s->pixSum, s->pixHits, s->fb, applyExposure);
+    if ((rc = endEvent(s, timing))) return rc;
+  }
+  if (timing) HIP_TRY(hipEventRecord(s->events[totalIdx].b, st));
+  HIP_TRY(hipGetLastError());
+  if (rgbaOut) HIP_TRY(hipMemcpyAsync(rgbaOut, s->fb, fbPixels * sizeof(float4), hipMemcpyDefault, st));
+  Counts hc{};
+  HIP_TRY(hipMemcpyAsync(&hc, s->counts, sizeof(Counts), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (hc.stackOverflow) return failMsg(RT_ERR_INVALID, "BVH traversal stack overflow (tree deeper than 64 pending nodes)");
+  if (stats) {
+    std::memset(stats, 0, sizeof *stats);
+    stats->cameraSamples = hc.samples;
+    stats->raysClosest = hc.raysClosest;
+    stats->raysAny = hc.raysAny;
+    stats->innerExpansions = hc.inner[0] + hc.inner[1];
+    stats->primTests = hc.prims[0] + hc.prims[1];
+    stats->planeTests = hc.planes[0] + hc.planes[1];
+    stats->raysExtend = hc.raysExtend; stats->raysShadow = hc.raysShadow;
+    stats->innerExtend = hc.inner[0]; stats->primExtend = hc.prims[0];
+    stats->innerShadow = hc.inner[1]; stats->primShadow = hc.prims[1];
+    stats->passes = passes;
+    stats->launchesExtend = launchesExtend;
+    stats->launchesShadow = launchesShadow;
+    double ms[CAT_COUNT] = {0};
+    for (size_t i = 0; i < s->eventsUsed; ++i) {
+      float t = 0;
+      HIP_TRY(hipEventElapsedTime(&t, s->events[i].a, s->events[i].b));
+      ms[s->events[i].category] += t;
+    }
+    stats->msTotal = ms[CAT_TOTAL]; stats->msRaygen = ms[CAT_RAYGEN]; stats->msExtend = ms[CAT_EXTEND];
+    stats->msShade = ms[CAT_SHADE]; stats->msShadow = ms[CAT_SHADOW]; stats->msAccumulate = ms[CAT_ACCUM];
+    stats->msResolve = ms[CAT_RESOLVE];
+  }
+  return RT_OK;
+}
+
+const float *rt_framebuffer_device(RtScene *s) { return s ? reinterpret_cast<const float *>(s->fb) : nullptr; }
+
+int rt_resolve_rgba8(RtScene *s, uint8_t *rgba8Out) {
+  if (!s || !rgba8Out) return failMsg(RT_ERR_INVALID, "null argument");
+  if (!s->fb) return failMsg(RT_ERR_INVALID, "rt_render has not run on this scene");
+  HIP_TRY(hipSetDevice(s->device));
+  int64_t n = (int64_t)s->dev.width * s->dev.height;
+  if (n > s->fbPixels) return failMsg(RT_ERR_INVALID, "framebuffer is smaller than the current image size");
+  uchar4 *d = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), n * 4));
+  k_srgb8<<<gridFor(n), kBlock, 0, s->stream>>>(s->fb, d, (int32_t)n);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(rgba8Out, d, n * 4, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return failMsg(RT_ERR_DEVICE, std::string("rt_resolve_rgba8: ") + hipGetErrorString(e));
+  return RT_OK;
+}
+
+}  // extern "C"

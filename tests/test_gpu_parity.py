@@ -1,0 +1,178 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): the HIP library, called through its C ABI, against the CPU
+restatement (oracle) on the same RtSceneDesc and against the fixtures generated from the compiled reference.
+
+Bars: primary hits and arbitrary closest/any queries are BIT-EXACT (ids, bits of t, hit point, normal);
+shaded images at matched counter-RNG streams: PSNR >= 40 dB over r,g,b (the tolerance north_star states), plus a
+bound on the fraction of pixels that differ visibly; tile partitions recombine bit-exactly."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from raytracer_amd import capi
+from tests.conftest import SMALL_SCENES, psnr
+from tests.oracle_binding import oracle_scene
+
+pytestmark = pytest.mark.gpu
+PSNR_MIN_DB = 40.0
+
+
+def sha1(a):
+    return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def scenes(scene_path):
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            hs = capi.HostScene.load(scene_path(name)).build()
+            cache[name] = (hs, capi.device_scene(hs.desc), oracle_scene(hs.desc))
+        return cache[name]
+    yield get
+    for hs, dev, orc in cache.values():
+        dev.close(); orc.close()
+
+
+@pytest.mark.parametrize("name", SMALL_SCENES)
+def test_primary_hits_bit_exact_vs_reference_fixture(name, scenes, golden):
+    g = golden(name)
+    _, dev, orc = scenes(name)
+    ids, t = dev.trace_primary()
+    assert np.array_equal(ids, g["hit_ids"]), f"{int((ids != g['hit_ids']).sum())} hit ids differ from the reference"
+    assert np.array_equal(t.view(np.uint32), g["hit_tbits"])
+    oids, ot = orc.trace_primary()
+    assert np.array_equal(ids, oids) and np.array_equal(t.view(np.uint32), ot.view(np.uint32))
+
+
+def test_primary_hits_config2_full_size(scenes, golden):
+    """BASELINE config 2: 1080x1080 primary rays on the ~70k-triangle mesh; every id and t bit pattern."""
+    g = golden("mesh70k")
+    _, dev, orc = scenes("mesh70k")
+    ids, t = dev.trace_primary()
+    assert int((ids >= 0).sum()) == int(g["num_hits"])
+    assert sha1(ids) == str(g["hit_ids_sha1"])
+    assert sha1(t.view(np.uint32)) == str(g["hit_tbits_sha1"])
+    # sub-rectangle addressing
+    ids2, t2 = dev.trace_primary(x0=500, y0=410, w=133, h=77)
+    assert np.array_equal(ids2, ids[410:487, 500:633]) and np.array_equal(t2.view(np.uint32), t[410:487, 500:633].view(np.uint32))
+
+
+def _random_rays(n, seed, spread=4.0):
+    rng = np.random.default_rng(seed)
+    o = (rng.normal(size=(n, 3)) * np.array([spread, spread * 0.6, spread]) + np.array([0, 0.3, -3])).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    # un-normalised directions of very different lengths, some axis-aligned (zero components -> infinite reciprocals)
+    d *= np.exp(rng.normal(size=(n, 1)) * 1.5).astype(np.float32)
+    d[::17, 0] = 0.0
+    d[5::29, 1] = 0.0
+    d[11::31, 2] = 0.0
+    return o, d
+
+
+@pytest.mark.parametrize("name", ["materials", "mesh1k", "spheres_txt", "readme_small", "mesh70k"])
+def test_incoherent_closest_and_any_queries_bit_exact(name, scenes):
+    _, dev, orc = scenes(name)
+    o, d = _random_rays(200_000 if name != "mesh70k" else 400_000, seed=hash(name) & 0xFFFF)
+    ids, t, pt, nm = dev.trace_closest(o, d)
+    oids, ot, opt, onm = orc.trace_closest(o, d)
+    assert np.array_equal(ids, oids), f"{int((ids != oids).sum())} ids differ"
+    assert np.array_equal(t.view(np.uint32), ot.view(np.uint32))
+    assert np.array_equal(pt.view(np.uint32), opt.view(np.uint32))
+    assert np.array_equal(nm.view(np.uint32), onm.view(np.uint32))
+    assert int((ids >= 0).sum()) > 1000
+    assert np.array_equal(dev.trace_any(o, d), orc.trace_any(o, d))
+
+
+@pytest.mark.parametrize("name", SMALL_SCENES)
+def test_render_matches_oracle_at_matched_streams(name, scenes):
+    """Counter RNG, same seed: same estimator, same random numbers; only the device libm differs."""
+    _, dev, orc = scenes(name)
+    img, st = dev.render(seed=56)
+    ref, ost = orc.render(seed=56)
+    assert img.shape == ref.shape
+    assert st.cameraSamples == ost.cameraSamples
+    p = psnr(img[..., :3], ref[..., :3])
+    assert p >= PSNR_MIN_DB, f"PSNR {p:.1f} dB"
+    # alpha is the hit mask (hits / numRays): exact
+    assert np.array_equal(img[..., 3], ref[..., 3])
+    # ray counts follow from the same path decisions; allow the few paths a 1-ulp libm difference redirects
+    assert abs(int(st.raysClosest + st.raysAny) - int(ost.raysClosest + ost.raysAny)) <= 0.002 * (ost.raysClosest + ost.raysAny) + 8
+    bad = np.abs(img[..., :3] - ref[..., :3]).max(-1) > 0.02
+    assert bad.mean() < 0.01, f"{bad.mean():.3%} of pixels differ by more than 0.02"
+
+
+def test_render_rng_free_scene_is_nearly_exact(scenes, golden):
+    """numRays 1, maxBounces 1, point light only: no random numbers reach the image; compare with the reference's own
+    framebuffer (any thread count gives the same image there)."""
+    _, dev, _ = scenes("config1_rngfree")
+    img, _ = dev.render()
+    g = golden("config1_rngfree")["render_f32"]
+    assert np.array_equal(img[..., 3], g[..., 3])
+    assert np.abs(img - g).max() < 1e-5
+    assert np.abs(dev.resolve_rgba8().astype(int) - golden("config1_rngfree")["render_rgba8"].astype(int)).max() <= 1
+
+
+def test_tile_partition_invariance(scenes):
+    """1/2/4/8-way tile partitions of the same frame recombine into the un-partitioned image, bit for bit."""
+    _, dev, _ = scenes("materials")
+    full, st = dev.render(seed=3)
+    for parts, tile in ((2, (32, 32)), (4, (16, 16)), (8, (8, 24))):
+        acc = np.zeros_like(full)
+        samples = 0
+        for k in range(parts):
+            img, s = dev.render(seed=3, part_index=k, part_count=parts, tile=tile)
+            assert np.all((acc == 0) | (img == 0))
+            acc += img
+            samples += s.cameraSamples
+        assert samples == st.cameraSamples
+        assert np.array_equal(acc.view(np.uint32), full.view(np.uint32)), f"{parts}-way partition changes the image"
+
+
+def test_samples_per_pass_does_not_change_the_image(scenes):
+    _, dev, _ = scenes("mesh1k_gi")
+    a, _ = dev.render(seed=9, samples_per_pass=1)
+    b, _ = dev.render(seed=9, samples_per_pass=3)
+    c, _ = dev.render(seed=9)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(a.view(np.uint32), c.view(np.uint32))
+
+
+def test_counters_match_oracle_work(scenes):
+    """With collectCounters the kernels count inner-node expansions and primitive tests under the reference's visit
+    rule; on an RNG-free scene they equal the CPU loop's counts exactly."""
+    _, dev, orc = scenes("config1_rngfree")
+    _, st = dev.render(collect_counters=True)
+    _, ost = orc.render()
+    assert (st.raysClosest, st.raysAny) == (ost.raysClosest, ost.raysAny)
+    assert st.innerExpansions == ost.innerExpansions
+    _, dev, orc = scenes("mesh1k")
+    _, st = dev.render(collect_counters=True)
+    _, ost = orc.render()
+    assert (st.raysClosest, st.raysAny, st.innerExpansions) == (ost.raysClosest, ost.raysAny, ost.innerExpansions)
+
+
+def test_empty_and_degenerate_scenes(tmp_path):
+    p = tmp_path / "empty.txt"; p.write_text("png 16 8 a.png\n")
+    hs = capi.HostScene.load(str(p)).build()
+    dev = capi.device_scene(hs.desc)
+    ids, t = dev.trace_primary()
+    assert np.all(ids == -1) and np.all(np.isinf(t))
+    img, _ = dev.render()
+    assert np.all(img == 0)
+    # one sphere (the BVH root is a leaf), environment light only: every miss is lit, alpha 1 everywhere
+    p = tmp_path / "one.txt"; p.write_text("png 32 32 a.png\naa 4\ncolor 0.5 0.6 0.7\nenvironment 5\ncolor 1 0 0\nsphere 0 0 -3 1\n")
+    hs = capi.HostScene.load(str(p)).build()
+    dev, orc = capi.device_scene(hs.desc), oracle_scene(hs.desc)
+    img, _ = dev.render(seed=2)
+    ref, _ = orc.render(seed=2)
+    assert np.all(img[..., 3] == 1.0)
+    assert psnr(img[..., :3], ref[..., :3]) >= PSNR_MIN_DB
+
+
+def test_hip_library_rejects_what_it_cannot_do(scenes):
+    _, dev, _ = scenes("config1")
+    with pytest.raises(RuntimeError, match="RT_RNG_COUNTER"):
+        dev.render(rng_mode=capi.RT_RNG_REF_MT19937)
+    with pytest.raises(RuntimeError, match="partIndex"):
+        dev.render(part_index=5, part_count=2)

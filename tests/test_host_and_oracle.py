@@ -1,0 +1,159 @@
+"""CPU-side tests: the host scene library and the CPU restatement (oracle) against fixtures generated from the
+compiled reference (tests/golden/*.npz, made by tools/make_golden.py), plus ABI export checks. No GPU needed."""
+import ctypes as C
+import hashlib
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.conftest import REPO, SMALL_SCENES, psnr
+from raytracer_amd import capi
+from tests.oracle_binding import oracle_scene
+
+
+def sha1(a):
+    return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("name", SMALL_SCENES + ["mesh70k"])
+def test_host_bvh_matches_reference(name, scene_path, golden):
+    """Same node array and same object permutation as BVH::BVH (src/acceleration/BVH.cpp:161-182) on the same file."""
+    g = golden(name)
+    hs = capi.HostScene.load(scene_path(name)).build()
+    d = hs.desc.contents
+    assert d.numNodes == int(g["num_nodes"]) and d.numPrims == int(g["num_prims"])
+    assert sha1(hs.nodes()) == str(g["bvh_nodes_sha1"])
+    assert sha1(hs.prim_orig_index()) == str(g["bvh_perm_sha1"])
+    assert f"BVH created with {d.numNodes} nodes on {d.numPrims} objects." in hs.log
+
+
+@pytest.mark.parametrize("name", SMALL_SCENES)
+def test_oracle_primary_hits_bit_exact(name, scene_path, golden):
+    """Hit ids and the bits of t equal what Scene::findClosestObject returns in the reference, for every pixel."""
+    g = golden(name)
+    osc = oracle_scene(capi.HostScene.load(scene_path(name)).build().desc)
+    ids, t = osc.trace_primary()
+    assert np.array_equal(ids, g["hit_ids"])
+    assert np.array_equal(t.view(np.uint32), g["hit_tbits"])
+
+
+def test_oracle_primary_hits_config2_hash(scene_path, golden):
+    """Config 2 (1080x1080, ~70k triangles): all 1,166,400 ids and t bit patterns, by hash."""
+    g = golden("mesh70k")
+    osc = oracle_scene(capi.HostScene.load(scene_path("mesh70k")).build().desc)
+    ids, t = osc.trace_primary()
+    assert int((ids >= 0).sum()) == int(g["num_hits"])
+    assert sha1(ids) == str(g["hit_ids_sha1"])
+    assert sha1(t.view(np.uint32)) == str(g["hit_tbits_sha1"])
+
+
+@pytest.mark.parametrize("name", SMALL_SCENES)
+def test_oracle_render_replays_reference_t1(name, scene_path, golden):
+    """ref-mt19937 mode: the float framebuffer of the reference at -t1, bit for bit, and the PNG bytes it would save."""
+    g = golden(name)
+    osc = oracle_scene(capi.HostScene.load(scene_path(name)).build().desc)
+    img, st = osc.render(rng_mode=capi.RT_RNG_REF_MT19937)
+    assert np.array_equal(img.view(np.uint32), g["render_f32"].view(np.uint32))
+    assert np.array_equal(osc.resolve_rgba8(), g["render_rgba8"])
+    assert st.raysClosest > 0
+
+
+def test_oracle_counter_mode_partition_invariant(scene_path):
+    """Counter RNG: the image does not depend on the tile partition or the thread count."""
+    hs = capi.HostScene.load(scene_path("materials")).build()
+    full, _ = oracle_scene(hs.desc, threads=3).render(seed=7)
+    acc = np.zeros_like(full)
+    for part in range(3):
+        img, _ = oracle_scene(hs.desc, threads=1 + part).render(seed=7, part_index=part, part_count=3, tile=(16, 8))
+        assert np.all((acc == 0) | (img == 0))
+        acc += img
+    assert np.array_equal(acc.view(np.uint32), full.view(np.uint32))
+
+
+def test_oracle_counter_mode_converges_to_reference_stream(scene_path, golden):
+    """Different random streams, same estimator: the counter-mode image is close to the -t1 image (loose bound;
+    it only guards against a broken generator)."""
+    g = golden("config1")
+    img, _ = oracle_scene(capi.HostScene.load(scene_path("config1")).build().desc).render(seed=1)
+    assert psnr(img[..., :3], g["render_f32"][..., :3]) > 20.0
+
+
+def test_png_pixels_roundtrip(tmp_path):
+    rng = np.random.default_rng(0)
+    rgba8 = rng.integers(0, 256, size=(37, 53, 4), dtype=np.uint8)
+    p = str(tmp_path / "t.png")
+    capi.png_write_rgba8(p, rgba8)
+    assert np.array_equal(capi.png_read_rgba8(p), rgba8)
+    lin = capi.png_read_linear(p)
+    # PNG::readFromFile: byte/255 then sRGB->linear on r,g,b (src/image/PNG.cpp:137-144, 14-18)
+    c = rgba8[..., :3].astype(np.float32) / np.float32(255)
+    cd = c.astype(np.float64)
+    ref = np.where(cd < 0.04045, cd / 12.92, ((cd + 0.055) / 1.055) ** 2.4).astype(np.float32)
+    assert np.allclose(lin[..., :3], ref, rtol=0, atol=1e-7)
+    assert np.array_equal(lin[..., 3], rgba8[..., 3].astype(np.float32) / np.float32(255))
+    # linear -> sRGB8 (PNG::saveToFile) inverts it exactly on 8-bit data
+    assert np.array_equal(capi.to_srgb8(lin), rgba8)
+
+
+def test_scene_errors(tmp_path):
+    with pytest.raises(RuntimeError, match="Couldn't open file"):
+        capi.HostScene.load(str(tmp_path / "missing.sdml"))
+    p = tmp_path / "x.foo"; p.write_text("png 1 1 a.png\n")
+    with pytest.raises(RuntimeError, match="Unrecognized file format"):
+        capi.HostScene.load(str(p))
+    p = tmp_path / "bad.txt"; p.write_text("jpg 4 4 a.png\n")
+    with pytest.raises(RuntimeError, match="Expected PNG image type"):
+        capi.HostScene.load(str(p))
+    p = tmp_path / "nowidth.sdml"; p.write_text("<Scene options={height: 4; filename: a.png}>\n</Scene>\n")
+    with pytest.raises(RuntimeError, match="width not provided"):
+        capi.HostScene.load(str(p))
+    # a material without lobes is refused (the reference would index bdfs[-1])
+    p = tmp_path / "reflective.txt"; p.write_text("png 4 4 a.png\nreflective\nsphere 0 0 -2 1\n")
+    with pytest.raises(RuntimeError, match="no BSDF lobes"):
+        capi.HostScene.load(str(p)).build()
+
+
+def test_empty_scene_and_planes_only(tmp_path):
+    p = tmp_path / "empty.txt"; p.write_text("png 8 8 a.png\n")
+    hs = capi.HostScene.load(str(p)).build()
+    assert hs.desc.contents.numPrims == 0 and hs.desc.contents.numNodes == 0
+    osc = oracle_scene(hs.desc)
+    ids, t = osc.trace_primary()
+    assert np.all(ids == -1) and np.all(np.isinf(t))
+    img, _ = osc.render()
+    assert np.all(img == 0)  # no light, no hit: transparent black everywhere
+    p = tmp_path / "plane.txt"; p.write_text("png 8 8 a.png\nsun 0 1 0\nplane 0 1 0 1\n")
+    osc = oracle_scene(capi.HostScene.load(str(p)).build().desc)
+    ids, _ = osc.trace_primary()
+    assert set(np.unique(ids)) == {-1, 0}  # plane k is reported as numPrims + k
+
+
+def _declared(header):
+    text = open(os.path.join(REPO, "include", header)).read()
+    return sorted(set(re.findall(r"\b(rth?_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_libraries_export_every_declared_symbol():
+    """Both shipped libraries load without a GPU and export exactly what include/*.h declares."""
+    host = C.CDLL(os.path.join(REPO, "raytracer_amd", "librt_host.so"))
+    for sym in _declared("rt_host.h"):
+        assert hasattr(host, sym), sym
+    dev = capi.load_device_library()
+    names = [s for s in _declared("rt_amd.h") if s.startswith("rt_")]
+    assert "rt_render" in names and "rt_trace_primary" in names
+    for sym in names:
+        assert hasattr(dev, sym), sym
+    assert b"gfx950" in dev.rt_version()
+    # the oracle mirrors the same entry points under rto_
+    from tests.oracle_binding import load_oracle_library
+    orc = load_oracle_library()
+    for sym in names:
+        assert hasattr(orc, "rto_" + sym[3:]), sym
+
+
+def test_device_library_does_not_link_the_oracle():
+    out = subprocess.run(["ldd", os.path.join(REPO, "raytracer_amd", "libraytracer_amd.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "amdhip64" in out
