@@ -300,7 +300,7 @@ __global__ void k_begin_pass(PathBuf B) {
   Counts *c = B.counts;
   c->nActive = 0; c->nNext = 0; c->nHit = 0;
 }
-__global__ void k_count_samples(PathBuf B) { B.counts->samples += B.counts->nActive; }
+__global__ void k_count_samples(PathBuf B, unsigned long long n) { B.counts->samples += n; }  // rejected fisheye samples count too
 
 // Per pixel: fold this pass's samples, in sample order, into the running sum (raytracer.cpp:48-51).
 __global__ __launch_bounds__(kBlock) void k_accumulate(PathBuf B, float4 *pixSum, int32_t *pixHits, int32_t sppThis) {
@@ -977,7 +977,7 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
     k_begin_pass<<<1, 1, 0, st>>>(B);
     if ((rc = beginEvent(s, CAT_RAYGEN, timing))) return rc;
     k_raygen<<<grid, kBlock, 0, st>>>(S, B, s->pixList, sBase, sppThis, params->seed);
-    k_count_samples<<<1, 1, 0, st>>>(B);
+    k_count_samples<<<1, 1, 0, st>>>(B, (unsigned long long)n);
     if ((rc = endEvent(s, timing))) return rc;
     uint32_t *qCur = B.qA, *qNext = B.qB;
     for (int bounce = 0; bounce < S.maxBounces; ++bounce) {
