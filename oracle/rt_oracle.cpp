@@ -147,9 +147,11 @@ struct Material { int type; std::vector<Lobe> lobes; };
 
 struct Counters {
   uint64_t raysClosest = 0, raysAny = 0, inner = 0, prims = 0, planes = 0, samples = 0, raysExtend = 0;
+  uint64_t innerExtend = 0, primExtend = 0;  // the part of inner/prims spent on path-extension queries
+  bool extending = false;
   void add(const Counters &o) {
     raysClosest += o.raysClosest; raysAny += o.raysAny; inner += o.inner; prims += o.prims; planes += o.planes; samples += o.samples;
-    raysExtend += o.raysExtend;
+    raysExtend += o.raysExtend; innerExtend += o.innerExtend; primExtend += o.primExtend;
   }
 };
 
@@ -520,6 +522,7 @@ Hit bvhClosest(const RtoScene &s, const V3 &origin, const V3 &direction) {  // :
         int end = sub.rightOrStart + sub.numObjects;
         for (int i = sub.rightOrStart; i < end; ++i) {
           ++c.prims;
+          if (c.extending) ++c.primExtend;
           Hit info = s.kind[i] == RT_PRIM_TRIANGLE ? intersectTriangle(s, i, origin, direction)
                                                    : intersectSphere(s, i, origin, direction);
           if (info.t < minDistance) {
@@ -529,6 +532,7 @@ Hit bvhClosest(const RtoScene &s, const V3 &origin, const V3 &direction) {  // :
         }
       } else {
         ++c.inner;
+        if (c.extending) ++c.innerExtend;
         int leftIdx = nodeIdx + 1;
         int rightIdx = sub.rightOrStart;
         const RtBvhNode &left = s.nodes[leftIdx];
@@ -672,7 +676,9 @@ RGBA raytrace(const RtoScene &s, const V3 &origin, const V3 &direction, Sampler 
   V3 rayDirection = direction;
   for (int bounces = 0; bounces < s.options.maxBounces; ++bounces) {
     ++ctr().raysExtend;
+    ctr().extending = true;
     Hit info = findClosestObject(s, rayOrigin, rayDirection);
+    ctr().extending = false;
     if (info.prim < 0) {
       for (const RtLight &l : s.lights) addAssign(L, emittedLight(s, l, rayDirection));
       break;
@@ -958,6 +964,8 @@ int rto_render(RtoScene *s, const RtRenderParams *params, float *rgbaOut, RtStat
     stats->planeTests = total.planes;
     stats->raysExtend = total.raysExtend;
     stats->raysShadow = total.raysClosest + total.raysAny - total.raysExtend;
+    stats->innerExtend = total.innerExtend; stats->primExtend = total.primExtend;
+    stats->innerShadow = total.inner - total.innerExtend; stats->primShadow = total.prims - total.primExtend;
   }
   return RT_OK;
 }

@@ -72,6 +72,7 @@ struct DevScene {
   float rootMin[3], rootMax[3];
   int32_t numPrims;
   int32_t hasSpheres;
+  int32_t boxesFinite;  // every node box coordinate is finite (enables the min/max slab test)
   int32_t numPlanes;
   const DevPlane *planes;
   // shading

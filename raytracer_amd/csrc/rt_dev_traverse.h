@@ -37,27 +37,6 @@ RT_DEV float intersectAABB(V3 o, V3 inv, float mnx, float mny, float mnz, float 
   return (tmax >= tmin && tmax > 0) ? tmin : kInf;
 }
 
-template <int K, int BLOCK>
-struct ShortStack {
-  static_assert((K & (K - 1)) == 0, "K must be a power of two");
-  uint2 *col;  // this lane's column in the block's LDS array: entry slot s lives at col[s * BLOCK]
-  uint2 spill[kMaxStack - K];
-  int sp, lo;  // entries [lo, sp) are in LDS (slot = index % K); entries [0, lo) are in `spill`
-  bool overflow;
-  RT_DEV void init(uint2 *ldsBase) { col = ldsBase + threadIdx.x; sp = 0; lo = 0; overflow = false; }
-  RT_DEV void push(float dist, int32_t ref) {
-    if (sp == kMaxStack) { overflow = true; return; }  // the reference would write past its arrays here
-    if (sp - lo == K) { spill[lo] = col[(lo & (K - 1)) * BLOCK]; ++lo; }
-    col[(sp & (K - 1)) * BLOCK] = make_uint2(__float_as_uint(dist), (uint32_t)ref);
-    ++sp;
-  }
-  RT_DEV uint2 pop() {
-    --sp;
-    if (sp < lo) { lo = sp; return spill[sp]; }
-    return col[(sp & (K - 1)) * BLOCK];
-  }
-};
-
 struct TravCounters {
   uint32_t inner, prims, planes;
 };
@@ -101,24 +80,70 @@ RT_DEV void intersectLeaf(const DevScene &S, int32_t start, int32_t count, V3 o,
   }
 }
 
-// Scene::findClosestObject (ANY = false, src/scene/raytracer.cpp:187-196) or the boolean of Scene::findAnyObject
-// (ANY = true, :174-185; returns at the first object the closest-hit loop would have accepted).
-template <bool ANY, bool COUNT, int K, int BLOCK>
-RT_DEV HitRec traverse(const DevScene &S, V3 o, V3 d, uint2 *ldsStack, TravCounters &tc, bool &stackOverflow) {
+// Slab test for rays whose reciprocal direction is finite and non-zero in every component (and whose origin is
+// finite): then no product below can be NaN, and IEEE minNum/maxNum (v_min_f32 / v_max_f32) return exactly what the
+// reference's compare-and-select chain returns, up to the sign of a zero, which no later comparison can see.
+RT_DEV float intersectAABBFinite(V3 o, V3 inv, float mnx, float mny, float mnz, float mxx, float mxy, float mxz) {
+  float tx_near = (mnx - o.x) * inv.x, tx_far = (mxx - o.x) * inv.x;
+  float ty_near = (mny - o.y) * inv.y, ty_far = (mxy - o.y) * inv.y;
+  float tz_near = (mnz - o.z) * inv.z, tz_far = (mxz - o.z) * inv.z;
+  float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx_near, tx_far), __builtin_fminf(ty_near, ty_far)),
+                               __builtin_fminf(tz_near, tz_far));
+  float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx_near, tx_far), __builtin_fmaxf(ty_near, ty_far)),
+                               __builtin_fmaxf(tz_near, tz_far));
+  return (tmax >= tmin && tmax > 0) ? tmin : kInf;
+}
+
+enum { TRAV_CLOSEST = 0, TRAV_ANY = 1, TRAV_POINT_LIGHT = 2 };
+
+// One traversal query.
+//   TRAV_CLOSEST      Scene::findClosestObject (src/scene/raytracer.cpp:187-196)
+//   TRAV_ANY          the boolean of Scene::findAnyObject (:174-185): returns at the first object the closest-hit loop
+//                     accepts; which objects get accepted first depends on the order, whether one exists does not
+//   TRAV_POINT_LIGHT  the closest-hit query of PointLight::pointInShadow (src/scene/Object.cpp:18-25), stopping at the
+//                     first accepted hit that already satisfies its predicate |origin - hit| < bulbDist. Every float
+//                     operation between t and that length is monotone in t, and later accepted hits only have smaller
+//                     t, so the final closest hit would satisfy the predicate too: same answer, less work.
+// RUNTIME_MODE = false compiles the TRAV_CLOSEST loop only (the path-extension kernel).
+template <bool RUNTIME_MODE, bool COUNT, int K, int BLOCK>
+RT_DEV HitRec traverse(const DevScene &S, V3 o, V3 d, int mode, float bulbDist, uint2 *ldsStack, TravCounters &tc,
+                       bool &stackOverflow) {
+  const bool any = RUNTIME_MODE && mode == TRAV_ANY;
+  const bool pointLight = RUNTIME_MODE && mode == TRAV_POINT_LIGHT;
   V3 nd = normalized(d);
   float tBest = kInf;
   int32_t primBest = -1;
+  bool done = false;  // early exit taken
   if (S.rootRef != kNoBvh) {
     V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // src/acceleration/BVH.cpp:293
+    const bool finite = S.boxesFinite && isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z) && inv.x != 0 && inv.y != 0 &&
+                        inv.z != 0 && isfinite(o.x) && isfinite(o.y) && isfinite(o.z);
     float rootDist = intersectAABB(o, inv, S.rootMin[0], S.rootMin[1], S.rootMin[2], S.rootMax[0], S.rootMax[1], S.rootMax[2]);
     if (rootDist < kInf) {
-      ShortStack<K, BLOCK> stk;
-      stk.init(ldsStack);
+      // Per-lane stack: entries [lo, sp) live in LDS (slot = index % K, one column per lane: entry slot s of lane l is
+      // ldsStack[s * BLOCK + l]), entries [0, lo) have been spilled to per-lane scratch. The indices are plain locals
+      // (registers); only the spill array is addressed dynamically.
+      static_assert((K & (K - 1)) == 0, "K must be a power of two");
+      uint2 spill[kMaxStack - K];
+      int sp = 0, lo = 0;
+      const int lane = threadIdx.x;
       int32_t cur = S.rootRef;
       bool alive = true;
+      auto push = [&](float dist, int32_t ref) {
+        if (sp == kMaxStack) { stackOverflow = true; return; }  // the reference would write past its arrays here
+        if (sp - lo == K) { spill[lo] = ldsStack[(lo & (K - 1)) * BLOCK + lane]; ++lo; }
+        ldsStack[(sp & (K - 1)) * BLOCK + lane] = make_uint2(__float_as_uint(dist), (uint32_t)ref);
+        ++sp;
+      };
       auto popNext = [&]() -> bool {
-        while (stk.sp > 0) {
-          uint2 e = stk.pop();
+        while (sp > 0) {
+          --sp;
+          // A spilled entry is first copied back into its LDS slot (rare), so that the read below is always one
+          // ds_read_b64 of one address; reading "LDS or spill" directly makes the compiler select between the two
+          // addresses and issue a generic (flat) load.
+          uint2 *slot = ldsStack + (sp & (K - 1)) * BLOCK + lane;
+          if (sp < lo) { lo = sp; *slot = spill[sp]; }
+          uint2 e = *slot;
           if (__uint_as_float(e.x) < tBest) { cur = (int32_t)e.y; return true; }
         }
         return false;
@@ -129,12 +154,18 @@ RT_DEV HitRec traverse(const DevScene &S, V3 o, V3 d, uint2 *ldsStack, TravCount
           const float4 *N = S.nodes + 4 * (int64_t)cur;
           float4 a = N[0], b = N[1], c = N[2];
           int4 r = reinterpret_cast<const int4 *>(N)[3];
-          float dl = intersectAABB(o, inv, a.x, a.y, a.z, a.w, b.x, b.y);
-          float dr = intersectAABB(o, inv, b.z, b.w, c.x, c.y, c.z, c.w);
+          float dl, dr;
+          if (finite) {
+            dl = intersectAABBFinite(o, inv, a.x, a.y, a.z, a.w, b.x, b.y);
+            dr = intersectAABBFinite(o, inv, b.z, b.w, c.x, c.y, c.z, c.w);
+          } else {
+            dl = intersectAABB(o, inv, a.x, a.y, a.z, a.w, b.x, b.y);
+            dr = intersectAABB(o, inv, b.z, b.w, c.x, c.y, c.z, c.w);
+          }
           bool hl = dl < tBest, hr = dr < tBest;
           if (hl && hr) {
             bool swap = dr < dl;
-            stk.push(swap ? dl : dr, swap ? r.x : r.y);
+            push(swap ? dl : dr, swap ? r.x : r.y);
             cur = swap ? r.y : r.x;
           } else if (hl) {
             cur = r.x;
@@ -152,14 +183,21 @@ RT_DEV HitRec traverse(const DevScene &S, V3 o, V3 d, uint2 *ldsStack, TravCount
           BigLeaf bl = S.bigLeaves[cur & 0x7fffffff];
           start = bl.start; count = bl.count;
         }
+        float tBefore = tBest;
         intersectLeaf<COUNT>(S, start, count, o, nd, tBest, primBest, tc);
-        if (ANY && primBest >= 0) break;
+        if (RUNTIME_MODE && tBest < tBefore) {
+          if (any) { done = true; break; }
+          if (pointLight) {
+            // |point - info.point| < |center - point| with info.point = t * nd + origin (src/scene/Object.cpp:22-24)
+            V3 hp = tBest * nd + o;
+            if (magnitude(o - hp) < bulbDist) { done = true; break; }
+          }
+        }
         alive = popNext();
       }
-      stackOverflow = stackOverflow || stk.overflow;
     }
   }
-  if (!(ANY && primBest >= 0)) {
+  if (!done) {
     for (int32_t k = 0; k < S.numPlanes; ++k) {
       // Plane::intersect, src/scene/Object.cpp:133-141
       if (COUNT) ++tc.planes;
@@ -169,7 +207,7 @@ RT_DEV HitRec traverse(const DevScene &S, V3 o, V3 d, uint2 *ldsStack, TravCount
       if (t < 0) continue;
       if (t < tBest) {
         tBest = t; primBest = S.numPrims + k;
-        if (ANY) break;
+        if (any) break;
       }
     }
   }

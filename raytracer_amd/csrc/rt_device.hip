@@ -7,7 +7,8 @@
 //   k_raygen      Scene::threadTaskDefault/Fisheye/DOF sample set-up (src/scene/raytracer.cpp:44-47, 92-103, 142-153)
 //   k_extend      Scene::findClosestObject for every live path (src/scene/raytracer.cpp:216)           <- traversal
 //   k_shade       miss -> environment; hit -> geometry, getColor, light sampling set-up, BSDF sample (:217-246)
-//   k_shadow      the visibility queries of Light::intensity (src/scene/Object.cpp:7-46) + L += beta * ...  <- traversal
+//   k_shadow      the visibility queries of Light::intensity (src/scene/Object.cpp:7-46), one per hit and light  <- traversal
+//   k_direct      L += beta * (getColor * sum of the visible lights' intensities) (:198-206, :231)
 //   k_advance     queue bookkeeping and ray counters
 //   k_accumulate  per-pixel sample average bookkeeping (:48-51), in sample order
 //   k_resolve     hits/alpha/clip (:54-59) and Scene::expose (:303-312) into the float RGBA framebuffer
@@ -18,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -45,8 +47,9 @@ struct PathBuf {
   uint32_t *rng;
   float *hitT;
   int32_t *hitPrim;
-  float4 *shPoint, *shNormal, *shColor, *shWeight;
-  float4 *envWi;  // [numEnvLights][P]
+  float4 *shPoint, *shColor, *shWeight;
+  float4 *envWi;   // [numEnvLights][P] hemisphere direction drawn for each environment light
+  float4 *lightC;  // [numLights][P] what each light contributes if it turns out to be visible
   uint32_t *qA, *qB, *qHit;
   Counts *counts;
   int32_t P, npix;
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(DevScene S, PathBuf B, const 
   if (i < B.counts->nActive) {
     uint32_t slot = queue[i];
     float4 o = B.rayO[slot], d = B.rayD[slot];
-    HitRec h = traverse<false, COUNT, kStackLds, kBlock>(S, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), ldsStack, tc, overflow);
+    HitRec h = traverse<false, COUNT, kStackLds, kBlock>(S, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), TRAV_CLOSEST, 0.0f, ldsStack, tc, overflow);
     B.hitT[slot] = h.t;
     B.hitPrim[slot] = h.prim;
   }
@@ -197,18 +200,30 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, PathBuf B, const u
       V3 biased = point + S.bias * outNormal;  // raytracer.cpp:228
       uint32_t rng = B.rng[slot];
       RGBA beta = rgba(B.beta[slot]);
-      // Inputs of the direct-light term, consumed by k_shadow: L += beta * (getColor(biased) * sum_lights intensity)
+      // Inputs of the direct-light term L += beta * (getColor(biased) * sum_lights intensity), finished by k_shadow once
+      // visibility is known. Each light's unshadowed intensity (src/scene/Object.cpp:12-16, 27-34, 41-46) is evaluated
+      // here, in light order, so that environment lights draw their hemisphere direction before the BSDF draws.
       RGBA color = getColor(S, prim, biased);
       B.shPoint[slot] = make_float4(biased.x, biased.y, biased.z, 0);
-      B.shNormal[slot] = make_float4(normal.x, normal.y, normal.z, 0);
       B.shColor[slot] = f4(color);
       B.shWeight[slot] = f4(beta);
-      // Environment lights draw their hemisphere direction here, in light order, before the BSDF draws (Object.cpp:42)
       for (int k = 0; k < S.numLights; ++k) {
-        if (S.lights[k].type == RT_LIGHT_ENVIRONMENT) {
+        const DevLight &l = S.lights[k];
+        RGBA lc = rgba(l.color[0], l.color[1], l.color[2], l.color[3]);
+        RGBA c;
+        if (l.type == RT_LIGHT_DISTANT) {
+          c = lc * clipDot(normal, v3(l.v));
+        } else if (l.type == RT_LIGHT_POINT) {
+          V3 lightDirection = v3(l.v) - biased;
+          float distance = magnitude(lightDirection);
+          float invDistance = 1.0f / (distance * distance);
+          c = lc * clipDot(normal, lightDirection) * invDistance;
+        } else {
           V3 wi = sampleHemisphere(normal, rng);
-          B.envWi[(int64_t)S.lights[k].envSlot * B.P + slot] = make_float4(wi.x, wi.y, wi.z, 0);
+          B.envWi[(int64_t)l.envSlot * B.P + slot] = make_float4(wi.x, wi.y, wi.z, 0);
+          c = emittedLight(S, l, wi) * clipDot(normal, wi);
         }
+        B.lightC[(int64_t)k * B.P + slot] = f4(c);
       }
       const DevMaterial &mat = S.materials[matIdx];
       if (mat.type == RT_MAT_METAL) mulAssign(beta, objColor);  // raytracer.cpp:233-234
@@ -237,52 +252,55 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, PathBuf B, const u
 }
 
 // ---------------------------------------------------------------------------------------------------- k_shadow
+// One visibility query per (hit path, light), light-major so that a wavefront traces rays toward the same light.
+// A light that turns out to be hidden has its stored contribution replaced by RGBAColor(0, 0, 0, 1).
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_shadow(DevScene S, PathBuf B) {
   __shared__ uint2 ldsStack[kStackLds * kBlock];
-  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   TravCounters tc = {0, 0, 0};
   bool overflow = false;
-  if (i < B.counts->nHit) {
-    uint32_t slot = B.qHit[i];
-    float4 p4 = B.shPoint[slot], n4 = B.shNormal[slot];
-    V3 point = v3(p4.x, p4.y, p4.z), n = v3(n4.x, n4.y, n4.z);
-    RGBA Lsum = rgba(0, 0, 0, 1);  // `RGBAColor L;` in Scene::illuminate, raytracer.cpp:199
-    for (int k = 0; k < S.numLights; ++k) {
-      const DevLight &l = S.lights[k];
-      RGBA lc = rgba(l.color[0], l.color[1], l.color[2], l.color[3]);
-      RGBA contrib = rgba(0, 0, 0, 1);
-      if (l.type == RT_LIGHT_DISTANT) {  // Object.cpp:7-16
-        V3 dir = v3(l.v);
-        HitRec h = traverse<true, COUNT, kStackLds, kBlock>(S, point, dir, ldsStack, tc, overflow);
-        if (h.prim < 0) contrib = lc * clipDot(n, dir);
-      } else if (l.type == RT_LIGHT_POINT) {  // Object.cpp:18-34
-        V3 lightDirection = v3(l.v) - point;
-        float intersectToBulbDist = magnitude(lightDirection);
-        HitRec h = traverse<false, COUNT, kStackLds, kBlock>(S, point, lightDirection, ldsStack, tc, overflow);
-        bool shadowed = false;
-        if (h.prim >= 0) {
-          V3 hp = h.t * normalized(lightDirection) + point;
-          shadowed = magnitude(point - hp) < intersectToBulbDist;
-        }
-        if (!shadowed) {
-          float distance = magnitude(lightDirection);
-          float invDistance = 1.0f / (distance * distance);
-          contrib = lc * clipDot(n, lightDirection) * invDistance;
-        }
-      } else {  // environment, Object.cpp:36-46
-        float4 w4 = B.envWi[(int64_t)l.envSlot * B.P + slot];
-        V3 wi = v3(w4.x, w4.y, w4.z);
-        HitRec h = traverse<true, COUNT, kStackLds, kBlock>(S, point, wi, ldsStack, tc, overflow);
-        if (h.prim < 0) contrib = emittedLight(S, l, wi) * clipDot(n, wi);
-      }
-      addAssign(Lsum, contrib);
+  uint32_t nHit = B.counts->nHit;
+  if (i < (uint64_t)nHit * S.numLights) {
+    int k = (int)(i / nHit);
+    uint32_t slot = B.qHit[i - (uint64_t)k * nHit];
+    const DevLight &l = S.lights[k];
+    float4 p4 = B.shPoint[slot];
+    V3 point = v3(p4.x, p4.y, p4.z);
+    V3 dir;
+    int mode = TRAV_ANY;
+    float bulbDist = 0.0f;
+    if (l.type == RT_LIGHT_DISTANT) {
+      dir = v3(l.v);  // Object.cpp:7-10
+    } else if (l.type == RT_LIGHT_POINT) {
+      dir = v3(l.v) - point;  // Object.cpp:18-25: closest hit along the un-normalised vector to the bulb
+      bulbDist = magnitude(dir);
+      mode = TRAV_POINT_LIGHT;
+    } else {
+      float4 w4 = B.envWi[(int64_t)l.envSlot * B.P + slot];  // Object.cpp:36-39, direction drawn in k_shade
+      dir = v3(w4.x, w4.y, w4.z);
     }
-    RGBA L = rgba(B.L[slot]);
-    addAssign(L, rgba(B.shWeight[slot]) * (rgba(B.shColor[slot]) * Lsum));  // raytracer.cpp:205, 231
-    B.L[slot] = f4(L);
+    HitRec h = traverse<true, COUNT, kStackLds, kBlock>(S, point, dir, mode, bulbDist, ldsStack, tc, overflow);
+    bool shadowed = h.prim >= 0;
+    if (mode == TRAV_POINT_LIGHT && shadowed) {
+      V3 hp = h.t * normalized(dir) + point;
+      shadowed = magnitude(point - hp) < bulbDist;
+    }
+    if (shadowed) B.lightC[(int64_t)k * B.P + slot] = make_float4(0, 0, 0, 1);
   }
   flushCounters<COUNT>(B.counts, tc, overflow, 1);
+}
+
+// L += beta * (getColor(point) * sum over lights, in scene order) — src/scene/raytracer.cpp:198-206, 231
+__global__ __launch_bounds__(kBlock) void k_direct(DevScene S, PathBuf B) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B.counts->nHit) return;
+  uint32_t slot = B.qHit[i];
+  RGBA Lsum = rgba(0, 0, 0, 1);  // `RGBAColor L;`
+  for (int k = 0; k < S.numLights; ++k) addAssign(Lsum, rgba(B.lightC[(int64_t)k * B.P + slot]));
+  RGBA L = rgba(B.L[slot]);
+  addAssign(L, rgba(B.shWeight[slot]) * (rgba(B.shColor[slot]) * Lsum));
+  B.L[slot] = f4(L);
 }
 
 // ---------------------------------------------------------------------------------------------------- bookkeeping
@@ -378,7 +396,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_primary(DevScene S, int32_t x0
     float Sx = getRayScaleX((float)x, S.width, S.height);
     float Sy = getRayScaleY((float)y, S.width, S.height);
     V3 d = v3(S.forward) + Sx * v3(S.right) + Sy * v3(S.up);
-    HitRec hr = traverse<false, false, kStackLds, kBlock>(S, v3(S.eye), d, ldsStack, tc, overflow);
+    HitRec hr = traverse<false, false, kStackLds, kBlock>(S, v3(S.eye), d, TRAV_CLOSEST, 0.0f, ldsStack, tc, overflow);
     int64_t j = (int64_t)row * w + col;
     outPrim[j] = reportedId(S, hr.prim);
     outT[j] = hr.t;
@@ -396,7 +414,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene S, int64_t n, co
   bool overflow = false;
   if (j < n) {
     V3 o = v3(origins + 3 * j), d = v3(directions + 3 * j);
-    HitRec hr = traverse<ANY, false, kStackLds, kBlock>(S, o, d, ldsStack, tc, overflow);
+    HitRec hr = traverse<ANY, false, kStackLds, kBlock>(S, o, d, ANY ? TRAV_ANY : TRAV_CLOSEST, 0.0f, ldsStack, tc, overflow);
     if (ANY) {
       outOccluded[j] = hr.prim >= 0 ? 1 : 0;
     } else {
@@ -448,7 +466,7 @@ struct EventPair {
   hipEvent_t a, b;
   int category;
 };
-enum { CAT_RAYGEN, CAT_EXTEND, CAT_SHADE, CAT_SHADOW, CAT_ACCUM, CAT_RESOLVE, CAT_TOTAL, CAT_COUNT };
+enum { CAT_RAYGEN, CAT_EXTEND, CAT_SHADE, CAT_SHADOW, CAT_DIRECT, CAT_ACCUM, CAT_RESOLVE, CAT_TOTAL, CAT_COUNT };
 
 }  // namespace
 
@@ -649,6 +667,10 @@ int buildScene(RtScene *s, const RtSceneDesc *d) {
   }
   dev.numPrims = d->numPrims;
   dev.hasSpheres = hasSpheres;
+  dev.boxesFinite = std::getenv("RT_EXACT_SLAB_TEST") ? 0 : 1;  // debugging aid: force the compare-and-select slab test
+  for (int32_t i = 0; i < d->numNodes; ++i)
+    for (int k = 0; k < 3; ++k)
+      if (!std::isfinite(d->nodes[i].aabbMin[k]) || !std::isfinite(d->nodes[i].aabbMax[k])) dev.boxesFinite = 0;
   int rc;
   if ((rc = upload(s, nodes.data(), nodes.size(), &dev.nodes))) return rc;
   if ((rc = upload(s, primHit.data(), primHit.size(), &dev.primHit))) return rc;
@@ -754,7 +776,8 @@ int ensureRenderBuffers(RtScene *s, int64_t P, int64_t npix, int64_t fbPixels) {
     if (s->arena) (void)hipFree(s->arena);
     s->arena = nullptr;
     int64_t nEnv = std::max(1, s->numEnvLights);
-    size_t bytes = (size_t)P * (sizeof(float4) * (8 + nEnv) + 4 * 6) + 4096;
+    int64_t nLights = std::max(1, s->dev.numLights);
+    size_t bytes = (size_t)P * (sizeof(float4) * (7 + nEnv + nLights) + 4 * 6) + 4096;
     HIP_TRY(hipMalloc(&s->arena, bytes));
     s->arenaBytes = bytes;
     s->arenaP = P;
@@ -769,10 +792,10 @@ int ensureRenderBuffers(RtScene *s, int64_t P, int64_t npix, int64_t fbPixels) {
   b.beta = reinterpret_cast<float4 *>(base); base += f4b;
   b.L = reinterpret_cast<float4 *>(base); base += f4b;
   b.shPoint = reinterpret_cast<float4 *>(base); base += f4b;
-  b.shNormal = reinterpret_cast<float4 *>(base); base += f4b;
   b.shColor = reinterpret_cast<float4 *>(base); base += f4b;
   b.shWeight = reinterpret_cast<float4 *>(base); base += f4b;
   b.envWi = reinterpret_cast<float4 *>(base); base += f4b * std::max(1, s->numEnvLights);
+  b.lightC = reinterpret_cast<float4 *>(base); base += f4b * std::max(1, s->dev.numLights);
   b.rng = reinterpret_cast<uint32_t *>(base); base += (size_t)cap * 4;
   b.hitT = reinterpret_cast<float *>(base); base += (size_t)cap * 4;
   b.hitPrim = reinterpret_cast<int32_t *>(base); base += (size_t)cap * 4;
@@ -991,11 +1014,15 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
       if ((rc = endEvent(s, timing))) return rc;
       if (S.numLights > 0) {
         if ((rc = beginEvent(s, CAT_SHADOW, timing))) return rc;
-        if (count) k_shadow<true><<<grid, kBlock, 0, st>>>(S, B);
-        else k_shadow<false><<<grid, kBlock, 0, st>>>(S, B);
+        unsigned gridShadow = gridFor(n * S.numLights);
+        if (count) k_shadow<true><<<gridShadow, kBlock, 0, st>>>(S, B);
+        else k_shadow<false><<<gridShadow, kBlock, 0, st>>>(S, B);
         if ((rc = endEvent(s, timing))) return rc;
         ++launchesShadow;
       }
+      if ((rc = beginEvent(s, CAT_DIRECT, timing))) return rc;
+      k_direct<<<grid, kBlock, 0, st>>>(S, B);
+      if ((rc = endEvent(s, timing))) return rc;
       k_advance<<<1, 1, 0, st>>>(B, s->numPointLights, s->numAnyLights);
       std::swap(qCur, qNext);
     }
@@ -1037,7 +1064,7 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
       ms[s->events[i].category] += t;
     }
     stats->msTotal = ms[CAT_TOTAL]; stats->msRaygen = ms[CAT_RAYGEN]; stats->msExtend = ms[CAT_EXTEND];
-    stats->msShade = ms[CAT_SHADE]; stats->msShadow = ms[CAT_SHADOW]; stats->msAccumulate = ms[CAT_ACCUM];
+    stats->msShade = ms[CAT_SHADE]; stats->msShadow = ms[CAT_SHADOW]; stats->msDirect = ms[CAT_DIRECT]; stats->msAccumulate = ms[CAT_ACCUM];
     stats->msResolve = ms[CAT_RESOLVE];
   }
   return RT_OK;

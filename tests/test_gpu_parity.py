@@ -139,17 +139,17 @@ def test_samples_per_pass_does_not_change_the_image(scenes):
 
 
 def test_counters_match_oracle_work(scenes):
-    """With collectCounters the kernels count inner-node expansions and primitive tests under the reference's visit
-    rule; on an RNG-free scene they equal the CPU loop's counts exactly."""
-    _, dev, orc = scenes("config1_rngfree")
-    _, st = dev.render(collect_counters=True)
-    _, ost = orc.render()
-    assert (st.raysClosest, st.raysAny) == (ost.raysClosest, ost.raysAny)
-    assert st.innerExpansions == ost.innerExpansions
-    _, dev, orc = scenes("mesh1k")
-    _, st = dev.render(collect_counters=True)
-    _, ost = orc.render()
-    assert (st.raysClosest, st.raysAny, st.innerExpansions) == (ost.raysClosest, ost.raysAny, ost.innerExpansions)
+    """With collectCounters the kernels count inner-node expansions and primitive tests. For path-extension queries
+    the visit rule is the reference's, so on RNG-free scenes the counts equal the CPU loop's exactly; point-light
+    visibility queries stop early on the GPU (same answer), so they can only do less work."""
+    for name in ("config1_rngfree", "mesh1k"):
+        _, dev, orc = scenes(name)
+        _, st = dev.render(collect_counters=True)
+        _, ost = orc.render()
+        assert (st.raysClosest, st.raysAny, st.raysExtend, st.raysShadow) == (ost.raysClosest, ost.raysAny, ost.raysExtend, ost.raysShadow)
+        assert (st.innerExtend, st.primExtend) == (ost.innerExtend, ost.primExtend)
+        assert st.innerShadow <= ost.innerShadow and st.primShadow <= ost.primShadow
+        assert st.innerExpansions == st.innerExtend + st.innerShadow
 
 
 def test_empty_and_degenerate_scenes(tmp_path):
