@@ -152,7 +152,9 @@ def main():
         "bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
         "bytes_per_ray": round(kb, 1), "rays_per_launch": round(krays / max(1, klaunch), 1),
-        "avg_launch_ms": round(kms / max(1, klaunch), 4), "mrays_per_s_in_kernel": round(krays / (kms * 1e-3) / 1e6, 1) if kms > 0 else 0.0,
+        "avg_launch_ms": round(kms / max(1, klaunch), 4),
+        "lane_use": {"extend_inner": round(cst.laneUseInnerExtend, 3), "extend_prim": round(cst.laneUsePrimExtend, 3),
+                     "shadow_inner": round(cst.laneUseInnerShadow, 3), "shadow_prim": round(cst.laneUsePrimShadow, 3)}, "mrays_per_s_in_kernel": round(krays / (kms * 1e-3) / 1e6, 1) if kms > 0 else 0.0,
         "other_kernel": {"kernel": "k_shadow" if kname == "k_extend" else "k_extend",
                          "bytes_per_ray": round(b_sh if kname == "k_extend" else b_ext, 1),
                          "ms_total": round(ms_sh if kname == "k_extend" else ms_ext, 2),

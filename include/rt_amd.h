@@ -154,6 +154,9 @@ typedef struct RtStats {
   double msRaygen, msExtend, msShade, msShadow, msDirect, msAccumulate, msResolve;
   uint32_t launchesExtend, launchesShadow;
   uint32_t passes;
+  /* only with collectCounters: average fraction of a wavefront's 64 lanes that do work in the inner-node loop and in
+   * the primitive-test loop, per traversal kernel (1.0 = no divergence loss) */
+  double laneUseInnerExtend, laneUsePrimExtend, laneUseInnerShadow, laneUsePrimShadow;
 } RtStats;
 
 typedef struct RtScene RtScene;

@@ -39,45 +39,44 @@ RT_DEV float intersectAABB(V3 o, V3 inv, float mnx, float mny, float mnz, float 
 
 struct TravCounters {
   uint32_t inner, prims, planes;
+  // wave-level iteration counts (each active lane adds 1/active, so the wave sums to 1 per iteration): with `inner`
+  // and `prims` they give the fraction of the 64 lanes doing useful work in the two hot loops
+  float innerWaveIters, primWaveIters;
 };
 
-// Tests the objects [start, start+count) against the ray and keeps the closest (strict <, array order).
-template <bool COUNT>
-RT_DEV void intersectLeaf(const DevScene &S, int32_t start, int32_t count, V3 o, V3 nd, float &tBest, int32_t &primBest,
-                          TravCounters &tc) {
-  for (int32_t i = start; i < start + count; ++i) {
-    if (COUNT) ++tc.prims;
-    const float4 *P = S.primHit + 3 * (int64_t)i;
-    float4 a = P[0], b = P[1], c = P[2];
-    float t;
-    bool sphere = S.hasSpheres && ((__float_as_uint(a.w) | __float_as_uint(b.x) | __float_as_uint(b.y)) == 0u);
-    if (!sphere) {
-      // Triangle::intersect, src/scene/Object.cpp:195-213 (direction normalised once per ray: same expression)
-      V3 p1 = v3(a.x, a.y, a.z), n = v3(a.w, b.x, b.y), e1 = v3(b.z, b.w, c.x), e2 = v3(c.y, c.z, c.w);
-      t = dot(p1 - o, n) / dot(nd, n);
-      if (t < 0) continue;
-      V3 q = (t * nd + o) - p1;
-      float b2 = dot(e1, q);
-      float b3 = dot(e2, q);
-      float b1 = 1.0f - b3 - b2;
-      if (b1 < 0 || b1 > 1 || b2 < 0 || b2 > 1 || b3 < 0 || b3 > 1) continue;
-    } else {
-      // Sphere::intersect, src/scene/Object.cpp:75-99
-      V3 center = v3(a.x, a.y, a.z);
-      float r = b.z;
-      float radiusSquared = r * r;
-      V3 dfs = center - o;
-      bool inside = dot(dfs, dfs) < radiusSquared;
-      float tcen = dot(dfs, nd);
-      if (inside == false && tcen < 0) continue;
-      V3 dd = (o + tcen * nd) - center;
-      float distanceSquared = dot(dd, dd);
-      if (inside == false && radiusSquared < distanceSquared) continue;
-      float tOffset = sqrtf(radiusSquared - distanceSquared);
-      t = inside ? tcen + tOffset : tcen - tOffset;
-    }
-    if (t < tBest) { tBest = t; primBest = i; }
+// Tests object i against the ray; returns true and updates the closest hit on a strict `<` (src/acceleration/BVH.cpp:309-313).
+RT_DEV bool intersectPrim(const DevScene &S, int32_t i, V3 o, V3 nd, float &tBest, int32_t &primBest) {
+  const float4 *P = S.primHit + 3 * (int64_t)i;
+  float4 a = P[0], b = P[1], c = P[2];
+  float t;
+  bool sphere = S.hasSpheres && ((__float_as_uint(a.w) | __float_as_uint(b.x) | __float_as_uint(b.y)) == 0u);
+  if (!sphere) {
+    // Triangle::intersect, src/scene/Object.cpp:195-213 (direction normalised once per ray: same expression)
+    V3 p1 = v3(a.x, a.y, a.z), n = v3(a.w, b.x, b.y), e1 = v3(b.z, b.w, c.x), e2 = v3(c.y, c.z, c.w);
+    t = dot(p1 - o, n) / dot(nd, n);
+    if (t < 0) return false;
+    V3 q = (t * nd + o) - p1;
+    float b2 = dot(e1, q);
+    float b3 = dot(e2, q);
+    float b1 = 1.0f - b3 - b2;
+    if (b1 < 0 || b1 > 1 || b2 < 0 || b2 > 1 || b3 < 0 || b3 > 1) return false;
+  } else {
+    // Sphere::intersect, src/scene/Object.cpp:75-99
+    V3 center = v3(a.x, a.y, a.z);
+    float r = b.z;
+    float radiusSquared = r * r;
+    V3 dfs = center - o;
+    bool inside = dot(dfs, dfs) < radiusSquared;
+    float tcen = dot(dfs, nd);
+    if (inside == false && tcen < 0) return false;
+    V3 dd = (o + tcen * nd) - center;
+    float distanceSquared = dot(dd, dd);
+    if (inside == false && radiusSquared < distanceSquared) return false;
+    float tOffset = sqrtf(radiusSquared - distanceSquared);
+    t = inside ? tcen + tOffset : tcen - tOffset;
   }
+  if (t < tBest) { tBest = t; primBest = i; return true; }
+  return false;
 }
 
 // Slab test for rays whose reciprocal direction is finite and non-zero in every component (and whose origin is
@@ -96,125 +95,205 @@ RT_DEV float intersectAABBFinite(V3 o, V3 inv, float mnx, float mny, float mnz, 
 
 enum { TRAV_CLOSEST = 0, TRAV_ANY = 1, TRAV_POINT_LIGHT = 2 };
 
-// One traversal query.
+// Scheduling thresholds of the traversal engine (lanes of one 64-lane wavefront).
+constexpr int kRefillMin = 16;  // idle lanes before the wavefront goes back to the queue
+constexpr int kFinishMin = 8;   // finished queries waiting before their results are written out
+
+// Traversal engine. Every wavefront pulls queries from a queue (one atomic per refill) and traces one query per lane.
+// Each lane always has exactly one pending operation:
+//     INNER   test the two child boxes of an inner node, descend / push / pop
+//     PRIM    test one object of the current leaf
+//     FINISH  planes + result write-out of a query whose BVH part is over
+//     IDLE    no query
+// and each loop iteration the whole wavefront executes ONE kind of operation, chosen by lane count: results are
+// written once kFinishMin lanes wait for it, the queue is visited once kRefillMin lanes are idle, otherwise the more
+// popular of INNER / PRIM runs and the minority waits until it has become the majority. Incoherent rays therefore do
+// not serialise the wavefront through both loop bodies every iteration, and a few long traversals do not leave most
+// lanes waiting: finished queries are REPLACED by new ones. Per query, nodes and objects are still visited in exactly
+// the reference's order. The grid is sized to fill the GPU once (persistent wavefronts); a wavefront ends when the
+// queue is exhausted and its own lanes are done, so nothing ever waits on another wavefront.
+//
+// Query kinds:
 //   TRAV_CLOSEST      Scene::findClosestObject (src/scene/raytracer.cpp:187-196)
-//   TRAV_ANY          the boolean of Scene::findAnyObject (:174-185): returns at the first object the closest-hit loop
-//                     accepts; which objects get accepted first depends on the order, whether one exists does not
+//   TRAV_ANY          the boolean of Scene::findAnyObject (:174-185): stops at the first object the closest-hit loop
+//                     accepts; which object that is depends on the order, whether one exists does not
 //   TRAV_POINT_LIGHT  the closest-hit query of PointLight::pointInShadow (src/scene/Object.cpp:18-25), stopping at the
 //                     first accepted hit that already satisfies its predicate |origin - hit| < bulbDist. Every float
 //                     operation between t and that length is monotone in t, and later accepted hits only have smaller
 //                     t, so the final closest hit would satisfy the predicate too: same answer, less work.
-// RUNTIME_MODE = false compiles the TRAV_CLOSEST loop only (the path-extension kernel).
-template <bool RUNTIME_MODE, bool COUNT, int K, int BLOCK>
-RT_DEV HitRec traverse(const DevScene &S, V3 o, V3 d, int mode, float bulbDist, uint2 *ldsStack, TravCounters &tc,
-                       bool &stackOverflow) {
-  const bool any = RUNTIME_MODE && mode == TRAV_ANY;
-  const bool pointLight = RUNTIME_MODE && mode == TRAV_POINT_LIGHT;
-  V3 nd = normalized(d);
-  float tBest = kInf;
-  int32_t primBest = -1;
-  bool done = false;  // early exit taken
-  if (S.rootRef != kNoBvh) {
-    V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // src/acceleration/BVH.cpp:293
-    const bool finite = S.boxesFinite && isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z) && inv.x != 0 && inv.y != 0 &&
-                        inv.z != 0 && isfinite(o.x) && isfinite(o.y) && isfinite(o.z);
-    float rootDist = intersectAABB(o, inv, S.rootMin[0], S.rootMin[1], S.rootMin[2], S.rootMax[0], S.rootMax[1], S.rootMax[2]);
-    if (rootDist < kInf) {
-      // Per-lane stack: entries [lo, sp) live in LDS (slot = index % K, one column per lane: entry slot s of lane l is
-      // ldsStack[s * BLOCK + l]), entries [0, lo) have been spilled to per-lane scratch. The indices are plain locals
-      // (registers); only the spill array is addressed dynamically.
-      static_assert((K & (K - 1)) == 0, "K must be a power of two");
-      uint2 spill[kMaxStack - K];
-      int sp = 0, lo = 0;
-      const int lane = threadIdx.x;
-      int32_t cur = S.rootRef;
-      bool alive = true;
-      auto push = [&](float dist, int32_t ref) {
-        if (sp == kMaxStack) { stackOverflow = true; return; }  // the reference would write past its arrays here
-        if (sp - lo == K) { spill[lo] = ldsStack[(lo & (K - 1)) * BLOCK + lane]; ++lo; }
-        ldsStack[(sp & (K - 1)) * BLOCK + lane] = make_uint2(__float_as_uint(dist), (uint32_t)ref);
-        ++sp;
-      };
-      auto popNext = [&]() -> bool {
-        while (sp > 0) {
-          --sp;
-          // A spilled entry is first copied back into its LDS slot (rare), so that the read below is always one
-          // ds_read_b64 of one address; reading "LDS or spill" directly makes the compiler select between the two
-          // addresses and issue a generic (flat) load.
-          uint2 *slot = ldsStack + (sp & (K - 1)) * BLOCK + lane;
-          if (sp < lo) { lo = sp; *slot = spill[sp]; }
-          uint2 e = *slot;
-          if (__uint_as_float(e.x) < tBest) { cur = (int32_t)e.y; return true; }
-        }
-        return false;
-      };
-      while (alive) {
-        while (alive && cur >= 0) {
-          if (COUNT) ++tc.inner;
-          const float4 *N = S.nodes + 4 * (int64_t)cur;
-          float4 a = N[0], b = N[1], c = N[2];
-          int4 r = reinterpret_cast<const int4 *>(N)[3];
-          float dl, dr;
-          if (finite) {
-            dl = intersectAABBFinite(o, inv, a.x, a.y, a.z, a.w, b.x, b.y);
-            dr = intersectAABBFinite(o, inv, b.z, b.w, c.x, c.y, c.z, c.w);
-          } else {
-            dl = intersectAABB(o, inv, a.x, a.y, a.z, a.w, b.x, b.y);
-            dr = intersectAABB(o, inv, b.z, b.w, c.x, c.y, c.z, c.w);
+// RUNTIME_MODE = false compiles the TRAV_CLOSEST loop only.
+//
+// Source (by reference):
+//   uint32_t total()                                                       number of queries in the queue
+//   uint32_t fetch(uint32_t idx, V3 &o, V3 &d, int &mode, float &bulbDist) load query idx, return a tag for store()
+//   void store(uint32_t tag, HitRec hit, bool occluded, V3 o, V3 nd)       deliver its result
+template <class Source, bool RUNTIME_MODE, bool COUNT, int K, int BLOCK>
+RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint2 *ldsStack, TravCounters &tc,
+                          bool &stackOverflow) {
+  static_assert((K & (K - 1)) == 0, "K must be a power of two");
+  const uint32_t total = src.total();
+  const int col = threadIdx.x;  // this lane's column of the LDS stack array
+  const uint32_t laneId = __lane_id();
+  // Per-lane stack: entries [lo, sp) live in LDS (slot = index % K; entry slot s of lane l is ldsStack[s * BLOCK + l],
+  // so lanes never share a bank), entries [0, lo) have been spilled to per-lane scratch. sp/lo are registers; only
+  // the spill array is addressed dynamically.
+  uint2 spill[kMaxStack - K];
+  enum { OP_IDLE = 0, OP_INNER = 1, OP_PRIM = 2, OP_FINISH = 3, OP_FINISH_EARLY = 4 };
+  int op = OP_IDLE;
+  uint32_t item = 0;
+  V3 o = v3(0, 0, 0), nd = o, inv = o;
+  float tBest = kInf, bulbDist = 0.0f;
+  int32_t primBest = -1, cur = 0, pi = 0, pe = 0;
+  int sp = 0, lo = 0, mode = TRAV_CLOSEST;
+  bool finite = false;
+  bool exhausted = false;  // wave-uniform: the queue has no more queries
+
+  while (true) {
+    bool needPop = false, haveNext = false;
+    int32_t next = 0;
+    unsigned long long mInner = __ballot(op == OP_INNER), mPrim = __ballot(op == OP_PRIM);
+    unsigned long long mFinish = __ballot(op >= OP_FINISH), mIdle = __ballot(op == OP_IDLE);
+    int nInner = __popcll(mInner), nPrim = __popcll(mPrim), nFinish = __popcll(mFinish), nIdle = __popcll(mIdle);
+
+    if (nFinish > 0 && (nFinish >= kFinishMin || nInner + nPrim == 0)) {
+      // ---------------------------------------------------------------- FINISH: planes, result, lane becomes idle
+      if (op >= OP_FINISH) {
+        bool occluded = op == OP_FINISH_EARLY;
+        if (op == OP_FINISH) {
+          for (int32_t k = 0; k < S.numPlanes; ++k) {
+            // Plane::intersect, src/scene/Object.cpp:133-141; planes lose ties to BVH objects (raytracer.cpp:192)
+            if (COUNT) ++tc.planes;
+            const DevPlane &pl = S.planes[k];
+            V3 pn = v3(pl.normal), pp = v3(pl.point);
+            float t = dot(pp - o, pn) / dot(nd, pn);
+            if (t < 0) continue;
+            if (t < tBest) {
+              tBest = t; primBest = S.numPrims + k;
+              if (RUNTIME_MODE && mode == TRAV_ANY) break;
+            }
           }
-          bool hl = dl < tBest, hr = dr < tBest;
-          if (hl && hr) {
-            bool swap = dr < dl;
-            push(swap ? dl : dr, swap ? r.x : r.y);
-            cur = swap ? r.y : r.x;
-          } else if (hl) {
-            cur = r.x;
-          } else if (hr) {
-            cur = r.y;
+          if (RUNTIME_MODE && mode == TRAV_POINT_LIGHT) {
+            // object hits were checked when they were accepted; only a plane can still satisfy the predicate
+            if (primBest >= S.numPrims) {
+              V3 hp = tBest * nd + o;
+              occluded = magnitude(o - hp) < bulbDist;
+            }
           } else {
-            alive = popNext();
+            occluded = primBest >= 0;
           }
         }
-        if (!alive) break;
-        int32_t start, count = (cur >> 24) & 0x7f;
-        if (count != 0) {
-          start = cur & 0xffffff;
+        HitRec h;
+        h.t = primBest >= 0 ? tBest : kInf;
+        h.prim = primBest;
+        src.store(item, h, occluded, o, nd);
+        op = OP_IDLE;
+      }
+    } else if (!exhausted && nIdle >= kRefillMin) {
+      // ---------------------------------------------------------------- REFILL idle lanes from the queue
+      int leader = __ffsll((long long)mIdle) - 1;
+      uint32_t base = 0;
+      if ((int)laneId == leader) base = atomicAdd(ticket, (uint32_t)nIdle);
+      base = __shfl(base, leader);
+      exhausted = base + (uint32_t)nIdle >= total;
+      uint32_t idx = base + (uint32_t)__popcll(mIdle & ((1ull << laneId) - 1ull));
+      if (op == OP_IDLE && idx < total) {
+        V3 d;
+        item = src.fetch(idx, o, d, mode, bulbDist);
+        nd = normalized(d);
+        tBest = kInf; primBest = -1; sp = 0; lo = 0;
+        op = OP_FINISH;
+        if (S.rootRef != kNoBvh) {
+          inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // src/acceleration/BVH.cpp:293
+          finite = S.boxesFinite && isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z) && inv.x != 0 && inv.y != 0 &&
+                   inv.z != 0 && isfinite(o.x) && isfinite(o.y) && isfinite(o.z);
+          float rootDist = intersectAABB(o, inv, S.rootMin[0], S.rootMin[1], S.rootMin[2], S.rootMax[0], S.rootMax[1], S.rootMax[2]);
+          if (rootDist < kInf) { next = S.rootRef; haveNext = true; }
+        }
+      }
+    } else if (nInner + nPrim == 0) {
+      break;  // nothing pending, nothing to finish, queue exhausted (or fewer idle lanes than a refill needs: none hold work)
+    } else if (nInner >= nPrim) {
+      // ---------------------------------------------------------------- INNER: both child boxes of the current node
+      if (op == OP_INNER) {
+        if (COUNT) { ++tc.inner; tc.innerWaveIters += 1.0f / (float)nInner; }
+        const float4 *N = S.nodes + 4 * (int64_t)cur;
+        float4 a = N[0], b = N[1], c = N[2];
+        int4 r = reinterpret_cast<const int4 *>(N)[3];
+        float dl, dr;
+        if (finite) {
+          dl = intersectAABBFinite(o, inv, a.x, a.y, a.z, a.w, b.x, b.y);
+          dr = intersectAABBFinite(o, inv, b.z, b.w, c.x, c.y, c.z, c.w);
         } else {
-          BigLeaf bl = S.bigLeaves[cur & 0x7fffffff];
-          start = bl.start; count = bl.count;
+          dl = intersectAABB(o, inv, a.x, a.y, a.z, a.w, b.x, b.y);
+          dr = intersectAABB(o, inv, b.z, b.w, c.x, c.y, c.z, c.w);
         }
-        float tBefore = tBest;
-        intersectLeaf<COUNT>(S, start, count, o, nd, tBest, primBest, tc);
-        if (RUNTIME_MODE && tBest < tBefore) {
-          if (any) { done = true; break; }
-          if (pointLight) {
+        // Near child first, right only if strictly nearer (src/acceleration/BVH.cpp:322-333); a child that cannot
+        // beat the closest hit any more is dropped here instead of at pop time.
+        bool hl = dl < tBest, hr = dr < tBest;
+        bool both = hl && hr;
+        bool swap = both && dr < dl;
+        if (both) {
+          if (sp == kMaxStack) {
+            stackOverflow = true;  // the reference would write past its arrays here
+          } else {
+            if (sp - lo == K) { spill[lo] = ldsStack[(lo & (K - 1)) * BLOCK + col]; ++lo; }
+            ldsStack[(sp & (K - 1)) * BLOCK + col] = make_uint2(__float_as_uint(swap ? dl : dr), (uint32_t)(swap ? r.x : r.y));
+            ++sp;
+          }
+        }
+        next = (hl && !swap) ? r.x : r.y;
+        haveNext = hl || hr;
+        needPop = !haveNext;
+      }
+    } else {
+      // ---------------------------------------------------------------- PRIM: one object of the current leaf
+      if (op == OP_PRIM) {
+        if (COUNT) { ++tc.prims; tc.primWaveIters += 1.0f / (float)nPrim; }
+        bool accepted = intersectPrim(S, pi, o, nd, tBest, primBest);
+        ++pi;
+        if (RUNTIME_MODE && accepted && mode != TRAV_CLOSEST) {
+          if (mode == TRAV_ANY) {
+            op = OP_FINISH_EARLY;
+          } else {
             // |point - info.point| < |center - point| with info.point = t * nd + origin (src/scene/Object.cpp:22-24)
             V3 hp = tBest * nd + o;
-            if (magnitude(o - hp) < bulbDist) { done = true; break; }
+            if (magnitude(o - hp) < bulbDist) op = OP_FINISH_EARLY;
           }
         }
-        alive = popNext();
+        needPop = op == OP_PRIM && pi == pe;
+      }
+    }
+    // ------------------------------------------------------------------ common tail: next node of lanes that need one
+    if (needPop) {
+      // next stack entry whose box entry distance is still below the closest hit (src/acceleration/BVH.cpp:302-305)
+      op = OP_FINISH;
+      while (sp > 0) {
+        --sp;
+        // A spilled entry is first copied back into its LDS slot (rare), so that the read below is always a plain LDS
+        // read of one address; reading "LDS or spill" directly makes the compiler select between the two addresses
+        // and issue a generic (flat) load.
+        uint2 *slot = ldsStack + (sp & (K - 1)) * BLOCK + col;
+        if (sp < lo) { lo = sp; *slot = spill[sp]; }
+        uint2 e = *slot;
+        if (__uint_as_float(e.x) < tBest) { next = (int32_t)e.y; haveNext = true; break; }
+      }
+    }
+    if (haveNext) {
+      // an inner node becomes an INNER operation, a leaf a run of PRIM operations
+      if (next >= 0) {
+        cur = next; op = OP_INNER;
+      } else {
+        int32_t count = (next >> 24) & 0x7f;
+        pi = next & 0xffffff;
+        if (count == 0) {
+          BigLeaf bl = S.bigLeaves[next & 0x7fffffff];
+          pi = bl.start; count = bl.count;
+        }
+        pe = pi + count;
+        op = OP_PRIM;
       }
     }
   }
-  if (!done) {
-    for (int32_t k = 0; k < S.numPlanes; ++k) {
-      // Plane::intersect, src/scene/Object.cpp:133-141
-      if (COUNT) ++tc.planes;
-      const DevPlane &pl = S.planes[k];
-      V3 pn = v3(pl.normal), pp = v3(pl.point);
-      float t = dot(pp - o, pn) / dot(nd, pn);
-      if (t < 0) continue;
-      if (t < tBest) {
-        tBest = t; primBest = S.numPrims + k;
-        if (any) break;
-      }
-    }
-  }
-  HitRec h;
-  h.t = primBest >= 0 ? tBest : kInf;
-  h.prim = primBest;
-  return h;
 }
 
 }  // namespace rtd

@@ -38,8 +38,10 @@ constexpr int kStackLds = 8;      // stack entries per lane kept in LDS (8 B eac
 
 struct Counts {
   uint32_t nActive, nNext, nHit, stackOverflow;
+  uint32_t ticket[4];  // next unclaimed queue index: [0] path extension, [1] light visibility, [2] trace-only kernels
   unsigned long long raysClosest, raysAny, samples, raysExtend, raysShadow;
   unsigned long long inner[2], prims[2], planes[2];  // [0] path extension, [1] light visibility
+  float innerWaveIters[2], primWaveIters[2];
 };
 
 struct PathBuf {
@@ -76,7 +78,12 @@ RT_DEV void flushCounters(Counts *c, const TravCounters &tc, bool overflow, int 
     for (int off = 32; off > 0; off >>= 1) {
       a += __shfl_down(a, off); b += __shfl_down(b, off); p += __shfl_down(p, off);
     }
-    if (__lane_id() == 0) { atomicAdd(&c->inner[kind], a); atomicAdd(&c->prims[kind], b); atomicAdd(&c->planes[kind], p); }
+    float wi = tc.innerWaveIters, wp = tc.primWaveIters;
+    for (int off = 32; off > 0; off >>= 1) { wi += __shfl_down(wi, off); wp += __shfl_down(wp, off); }
+    if (__lane_id() == 0) {
+      atomicAdd(&c->inner[kind], a); atomicAdd(&c->prims[kind], b); atomicAdd(&c->planes[kind], p);
+      atomicAdd(&c->innerWaveIters[kind], wi); atomicAdd(&c->primWaveIters[kind], wp);
+    }
   }
   if (overflow) atomicOr(&c->stackOverflow, 1u);
 }
@@ -131,19 +138,30 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DevScene S, PathBuf B, const 
 }
 
 // ---------------------------------------------------------------------------------------------------- k_extend
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_extend(DevScene S, PathBuf B, const uint32_t *queue) {
-  __shared__ uint2 ldsStack[kStackLds * kBlock];
-  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  TravCounters tc = {0, 0, 0};
-  bool overflow = false;
-  if (i < B.counts->nActive) {
-    uint32_t slot = queue[i];
-    float4 o = B.rayO[slot], d = B.rayD[slot];
-    HitRec h = traverse<false, COUNT, kStackLds, kBlock>(S, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), TRAV_CLOSEST, 0.0f, ldsStack, tc, overflow);
+struct ExtendSource {
+  const PathBuf &B;
+  const uint32_t *queue;
+  RT_DEV uint32_t total() const { return B.counts->nActive; }
+  RT_DEV uint32_t fetch(uint32_t idx, V3 &o, V3 &d, int &mode, float &bulbDist) const {
+    uint32_t slot = queue[idx];
+    float4 o4 = B.rayO[slot], d4 = B.rayD[slot];
+    o = v3(o4.x, o4.y, o4.z); d = v3(d4.x, d4.y, d4.z);
+    mode = TRAV_CLOSEST; bulbDist = 0.0f;
+    return slot;
+  }
+  RT_DEV void store(uint32_t slot, HitRec h, bool, V3, V3) const {
     B.hitT[slot] = h.t;
     B.hitPrim[slot] = h.prim;
   }
+};
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_extend(DevScene S, PathBuf B, const uint32_t *queue) {
+  __shared__ uint2 ldsStack[kStackLds * kBlock];
+  TravCounters tc = {0, 0, 0, 0.0f, 0.0f};
+  bool overflow = false;
+  ExtendSource src{B, queue};
+  traverseQueue<ExtendSource, false, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[0], ldsStack, tc, overflow);
   flushCounters<COUNT>(B.counts, tc, overflow, 0);
 }
 
@@ -254,40 +272,45 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, PathBuf B, const u
 // ---------------------------------------------------------------------------------------------------- k_shadow
 // One visibility query per (hit path, light), light-major so that a wavefront traces rays toward the same light.
 // A light that turns out to be hidden has its stored contribution replaced by RGBAColor(0, 0, 0, 1).
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_shadow(DevScene S, PathBuf B) {
-  __shared__ uint2 ldsStack[kStackLds * kBlock];
-  uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  TravCounters tc = {0, 0, 0};
-  bool overflow = false;
-  uint32_t nHit = B.counts->nHit;
-  if (i < (uint64_t)nHit * S.numLights) {
-    int k = (int)(i / nHit);
-    uint32_t slot = B.qHit[i - (uint64_t)k * nHit];
+struct ShadowSource {
+  const DevScene &S;
+  const PathBuf &B;
+  uint32_t nHit;
+  RT_DEV uint32_t total() const { return nHit * (uint32_t)S.numLights; }
+  RT_DEV uint32_t fetch(uint32_t idx, V3 &o, V3 &d, int &mode, float &bulbDist) const {
+    uint32_t k = idx / nHit;
+    uint32_t slot = B.qHit[idx - k * nHit];
     const DevLight &l = S.lights[k];
     float4 p4 = B.shPoint[slot];
-    V3 point = v3(p4.x, p4.y, p4.z);
-    V3 dir;
-    int mode = TRAV_ANY;
-    float bulbDist = 0.0f;
+    o = v3(p4.x, p4.y, p4.z);
+    mode = TRAV_ANY; bulbDist = 0.0f;
     if (l.type == RT_LIGHT_DISTANT) {
-      dir = v3(l.v);  // Object.cpp:7-10
+      d = v3(l.v);  // Object.cpp:7-10
     } else if (l.type == RT_LIGHT_POINT) {
-      dir = v3(l.v) - point;  // Object.cpp:18-25: closest hit along the un-normalised vector to the bulb
-      bulbDist = magnitude(dir);
+      d = v3(l.v) - o;  // Object.cpp:18-25: closest hit along the un-normalised vector to the bulb
+      bulbDist = magnitude(d);
       mode = TRAV_POINT_LIGHT;
     } else {
       float4 w4 = B.envWi[(int64_t)l.envSlot * B.P + slot];  // Object.cpp:36-39, direction drawn in k_shade
-      dir = v3(w4.x, w4.y, w4.z);
+      d = v3(w4.x, w4.y, w4.z);
     }
-    HitRec h = traverse<true, COUNT, kStackLds, kBlock>(S, point, dir, mode, bulbDist, ldsStack, tc, overflow);
-    bool shadowed = h.prim >= 0;
-    if (mode == TRAV_POINT_LIGHT && shadowed) {
-      V3 hp = h.t * normalized(dir) + point;
-      shadowed = magnitude(point - hp) < bulbDist;
-    }
-    if (shadowed) B.lightC[(int64_t)k * B.P + slot] = make_float4(0, 0, 0, 1);
+    return idx;
   }
+  RT_DEV void store(uint32_t idx, HitRec, bool occluded, V3, V3) const {
+    if (!occluded) return;
+    uint32_t k = idx / nHit;
+    uint32_t slot = B.qHit[idx - k * nHit];
+    B.lightC[(int64_t)k * B.P + slot] = make_float4(0, 0, 0, 1);
+  }
+};
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_shadow(DevScene S, PathBuf B) {
+  __shared__ uint2 ldsStack[kStackLds * kBlock];
+  TravCounters tc = {0, 0, 0, 0.0f, 0.0f};
+  bool overflow = false;
+  ShadowSource src{S, B, B.counts->nHit};
+  traverseQueue<ShadowSource, true, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[1], ldsStack, tc, overflow);
   flushCounters<COUNT>(B.counts, tc, overflow, 1);
 }
 
@@ -313,11 +336,14 @@ __global__ void k_advance(PathBuf B, int32_t numPointLights, int32_t numAnyLight
   c->nActive = c->nNext;
   c->nNext = 0;
   c->nHit = 0;
+  c->ticket[0] = 0; c->ticket[1] = 0;
 }
 __global__ void k_begin_pass(PathBuf B) {
   Counts *c = B.counts;
   c->nActive = 0; c->nNext = 0; c->nHit = 0;
+  c->ticket[0] = 0; c->ticket[1] = 0;
 }
+__global__ void k_reset_trace_ticket(Counts *c) { c->ticket[2] = 0; }
 __global__ void k_count_samples(PathBuf B, unsigned long long n) { B.counts->samples += n; }  // rejected fisheye samples count too
 
 // Per pixel: fold this pass's samples, in sample order, into the running sum (raytracer.cpp:48-51).
@@ -382,69 +408,99 @@ RT_DEV int32_t reportedId(const DevScene &S, int32_t prim) {
   return prim < 0 ? -1 : (prim < S.numPrims ? S.primOrigIndex[prim] : prim);
 }
 
-__global__ __launch_bounds__(kBlock) void k_trace_primary(DevScene S, int32_t x0, int32_t y0, int32_t w, int32_t h,
-                                                          int32_t *outPrim, float *outT, Counts *counts) {
-  __shared__ uint2 ldsStack[kStackLds * kBlock];
-  // 8x8 pixel tiles per wavefront: neighbouring lanes walk the same part of the tree
-  int32_t tilesX = (w + 7) / 8;
-  int32_t wave = (blockIdx.x * kBlock + threadIdx.x) / 64, lane = threadIdx.x & 63;
-  int32_t col = (wave % tilesX) * 8 + (lane & 7), row = (wave / tilesX) * 8 + (lane >> 3);
-  TravCounters tc = {0, 0, 0};
-  bool overflow = false;
-  if (col < w && row < h) {
-    int32_t x = x0 + col, y = y0 + row;
-    float Sx = getRayScaleX((float)x, S.width, S.height);
-    float Sy = getRayScaleY((float)y, S.width, S.height);
-    V3 d = v3(S.forward) + Sx * v3(S.right) + Sy * v3(S.up);
-    HitRec hr = traverse<false, false, kStackLds, kBlock>(S, v3(S.eye), d, TRAV_CLOSEST, 0.0f, ldsStack, tc, overflow);
-    int64_t j = (int64_t)row * w + col;
+struct PrimarySource {
+  const DevScene &S;
+  int32_t x0, y0, w, h;
+  int32_t *outPrim;
+  float *outT;
+  // 8x8 pixel blocks per 64 consecutive queries: neighbouring lanes walk the same part of the tree
+  RT_DEV uint32_t total() const { return (uint32_t)(((w + 7) / 8) * ((h + 7) / 8)) * 64u; }
+  RT_DEV uint32_t fetch(uint32_t idx, V3 &o, V3 &d, int &mode, float &bulbDist) const {
+    int32_t tilesX = (w + 7) / 8;
+    int32_t tile = (int32_t)(idx / 64u), l = (int32_t)(idx & 63u);
+    int32_t col = (tile % tilesX) * 8 + (l & 7), row = (tile / tilesX) * 8 + (l >> 3);
+    mode = TRAV_CLOSEST; bulbDist = 0.0f;
+    o = v3(S.eye);
+    if (col >= w || row >= h) {
+      // padding lane of a partial block: a NaN origin fails every box and plane comparison, so the query ends at once
+      o = v3(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+      d = v3(1, 0, 0);
+      return 0xffffffffu;
+    }
+    float Sx = getRayScaleX((float)(x0 + col), S.width, S.height);
+    float Sy = getRayScaleY((float)(y0 + row), S.width, S.height);
+    d = v3(S.forward) + Sx * v3(S.right) + Sy * v3(S.up);
+    return (uint32_t)(row * w + col);
+  }
+  RT_DEV void store(uint32_t j, HitRec hr, bool, V3, V3) const {
+    if (j == 0xffffffffu) return;
     outPrim[j] = reportedId(S, hr.prim);
     outT[j] = hr.t;
   }
+};
+
+__global__ __launch_bounds__(kBlock) void k_trace_primary(DevScene S, int32_t x0, int32_t y0, int32_t w, int32_t h,
+                                                          int32_t *outPrim, float *outT, Counts *counts) {
+  __shared__ uint2 ldsStack[kStackLds * kBlock];
+  TravCounters tc = {0, 0, 0, 0.0f, 0.0f};
+  bool overflow = false;
+  PrimarySource src{S, x0, y0, w, h, outPrim, outT};
+  traverseQueue<PrimarySource, false, false, kStackLds, kBlock>(S, src, &counts->ticket[2], ldsStack, tc, overflow);
   flushCounters<false>(counts, tc, overflow, 0);
 }
+
+template <bool ANY>
+struct RaysSource {
+  const DevScene &S;
+  int64_t n;
+  const float *origins, *directions;
+  int32_t *outPrim;
+  float *outT, *outPoint, *outNormal;
+  uint8_t *outOccluded;
+  RT_DEV uint32_t total() const { return (uint32_t)n; }
+  RT_DEV uint32_t fetch(uint32_t j, V3 &o, V3 &d, int &mode, float &bulbDist) const {
+    o = v3(origins + 3 * (int64_t)j); d = v3(directions + 3 * (int64_t)j);
+    mode = ANY ? TRAV_ANY : TRAV_CLOSEST; bulbDist = 0.0f;
+    return j;
+  }
+  RT_DEV void store(uint32_t j, HitRec hr, bool occluded, V3 o, V3 nd) const {
+    if (ANY) { outOccluded[j] = occluded ? 1 : 0; return; }
+    if (outPrim) outPrim[j] = reportedId(S, hr.prim);
+    if (outT) outT[j] = hr.t;
+    V3 point = v3(0, 0, 0), normal = v3(0, 0, 0);
+    if (hr.prim >= 0 && (outPoint || outNormal)) {
+      point = hr.t * nd + o;
+      if (hr.prim >= S.numPrims) {
+        normal = v3(S.planes[hr.prim - S.numPrims].normal);
+      } else {
+        const float4 *P = S.primHit + 3 * (int64_t)hr.prim;
+        float4 a = P[0], b = P[1], c = P[2];
+        if ((__float_as_uint(a.w) | __float_as_uint(b.x) | __float_as_uint(b.y)) == 0u) {
+          normal = normalized(point - v3(a.x, a.y, a.z));
+        } else {
+          V3 p1 = v3(a.x, a.y, a.z), e1 = v3(b.z, b.w, c.x), e2 = v3(c.y, c.z, c.w);
+          V3 q = point - p1;
+          float b2 = dot(e1, q), b3 = dot(e2, q);
+          float b1 = 1.0f - b3 - b2;
+          const float *nn = S.primNormals + 9 * (int64_t)hr.prim;
+          normal = normalized(v3(nn) * b1 + v3(nn + 3) * b2 + v3(nn + 6) * b3);
+        }
+      }
+    }
+    if (outPoint) { outPoint[3 * (int64_t)j] = point.x; outPoint[3 * (int64_t)j + 1] = point.y; outPoint[3 * (int64_t)j + 2] = point.z; }
+    if (outNormal) { outNormal[3 * (int64_t)j] = normal.x; outNormal[3 * (int64_t)j + 1] = normal.y; outNormal[3 * (int64_t)j + 2] = normal.z; }
+  }
+};
 
 template <bool ANY>
 __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene S, int64_t n, const float *origins, const float *directions,
                                                        int32_t *outPrim, float *outT, float *outPoint, float *outNormal,
                                                        uint8_t *outOccluded, Counts *counts) {
   __shared__ uint2 ldsStack[kStackLds * kBlock];
-  int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  TravCounters tc = {0, 0, 0};
+  TravCounters tc = {0, 0, 0, 0.0f, 0.0f};
   bool overflow = false;
-  if (j < n) {
-    V3 o = v3(origins + 3 * j), d = v3(directions + 3 * j);
-    HitRec hr = traverse<ANY, false, kStackLds, kBlock>(S, o, d, ANY ? TRAV_ANY : TRAV_CLOSEST, 0.0f, ldsStack, tc, overflow);
-    if (ANY) {
-      outOccluded[j] = hr.prim >= 0 ? 1 : 0;
-    } else {
-      if (outPrim) outPrim[j] = reportedId(S, hr.prim);
-      if (outT) outT[j] = hr.t;
-      V3 point = v3(0, 0, 0), normal = v3(0, 0, 0);
-      if (hr.prim >= 0 && (outPoint || outNormal)) {
-        V3 nd = normalized(d);
-        point = hr.t * nd + o;
-        if (hr.prim >= S.numPrims) {
-          normal = v3(S.planes[hr.prim - S.numPrims].normal);
-        } else {
-          const float4 *P = S.primHit + 3 * (int64_t)hr.prim;
-          float4 a = P[0], b = P[1], c = P[2];
-          if ((__float_as_uint(a.w) | __float_as_uint(b.x) | __float_as_uint(b.y)) == 0u) {
-            normal = normalized(point - v3(a.x, a.y, a.z));
-          } else {
-            V3 p1 = v3(a.x, a.y, a.z), e1 = v3(b.z, b.w, c.x), e2 = v3(c.y, c.z, c.w);
-            V3 q = point - p1;
-            float b2 = dot(e1, q), b3 = dot(e2, q);
-            float b1 = 1.0f - b3 - b2;
-            const float *nn = S.primNormals + 9 * (int64_t)hr.prim;
-            normal = normalized(v3(nn) * b1 + v3(nn + 3) * b2 + v3(nn + 6) * b3);
-          }
-        }
-      }
-      if (outPoint) { outPoint[3 * j] = point.x; outPoint[3 * j + 1] = point.y; outPoint[3 * j + 2] = point.z; }
-      if (outNormal) { outNormal[3 * j] = normal.x; outNormal[3 * j + 1] = normal.y; outNormal[3 * j + 2] = normal.z; }
-    }
-  }
+  RaysSource<ANY> src{S, n, origins, directions, outPrim, outT, outPoint, outNormal, outOccluded};
+  traverseQueue<RaysSource<ANY>, ANY, false, kStackLds, kBlock>(S, src, &counts->ticket[2], ldsStack, tc, overflow);
   flushCounters<false>(counts, tc, overflow, 0);
 }
 
@@ -476,6 +532,7 @@ struct RtScene {
   DevScene dev{};
   std::vector<void *> allocs;
   int32_t numPointLights = 0, numAnyLights = 0, numEnvLights = 0;
+  int numCUs = 256;
   // render state (allocated on first use, grown when needed)
   PathBuf buf{};
   void *arena = nullptr;
@@ -828,6 +885,11 @@ int endEvent(RtScene *s, bool enabled) {
 }
 
 inline unsigned gridFor(int64_t n) { return (unsigned)std::max<int64_t>(1, (n + kBlock - 1) / kBlock); }
+// Traversal kernels are persistent: enough blocks to fill every CU once (8 blocks of 4 wavefronts = the 32-wave limit),
+// fewer when the queue cannot feed them.
+inline unsigned persistentGrid(const RtScene *s, int64_t n) {
+  return (unsigned)std::min<int64_t>(gridFor(n), (int64_t)s->numCUs * 8);
+}
 
 }  // namespace
 
@@ -845,6 +907,8 @@ RtScene *rt_scene_create(const RtSceneDesc *desc, int device) {
   if ((e = hipSetDevice(device)) != hipSuccess) { g_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return nullptr; }
   auto s = std::make_unique<RtScene>();
   s->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->numCUs = prop.multiProcessorCount;
   if ((e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)) != hipSuccess) {
     g_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
     return nullptr;
@@ -900,7 +964,8 @@ int rt_trace_primary(RtScene *s, int32_t x0, int32_t y0, int32_t w, int32_t h, i
   HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dPrim), n * 4));
   HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dT), n * 4));
   int64_t waves = (int64_t)((w + 7) / 8) * ((h + 7) / 8);
-  k_trace_primary<<<gridFor(waves * 64), kBlock, 0, s->stream>>>(s->dev, x0, y0, w, h, dPrim, dT, s->counts);
+  k_reset_trace_ticket<<<1, 1, 0, s->stream>>>(s->counts);
+  k_trace_primary<<<persistentGrid(s, waves * 64), kBlock, 0, s->stream>>>(s->dev, x0, y0, w, h, dPrim, dT, s->counts);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(primId, dPrim, n * 4, hipMemcpyDeviceToHost, s->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(t, dT, n * 4, hipMemcpyDeviceToHost, s->stream);
@@ -933,8 +998,9 @@ static int traceRays(RtScene *s, bool any, int64_t n, const float *origins, cons
   if (e == hipSuccess) e = hipMemcpyAsync(dO, origins, n * 12, hipMemcpyHostToDevice, s->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(dD, directions, n * 12, hipMemcpyHostToDevice, s->stream);
   if (e == hipSuccess) {
-    if (any) k_trace_rays<true><<<gridFor(n), kBlock, 0, s->stream>>>(s->dev, n, dO, dD, nullptr, nullptr, nullptr, nullptr, dOcc, s->counts);
-    else k_trace_rays<false><<<gridFor(n), kBlock, 0, s->stream>>>(s->dev, n, dO, dD, dPrim, dT, dP, dN, nullptr, s->counts);
+    k_reset_trace_ticket<<<1, 1, 0, s->stream>>>(s->counts);
+    if (any) k_trace_rays<true><<<persistentGrid(s, n), kBlock, 0, s->stream>>>(s->dev, n, dO, dD, nullptr, nullptr, nullptr, nullptr, dOcc, s->counts);
+    else k_trace_rays<false><<<persistentGrid(s, n), kBlock, 0, s->stream>>>(s->dev, n, dO, dD, dPrim, dT, dP, dN, nullptr, s->counts);
     e = hipGetLastError();
   }
   if (e == hipSuccess && dOcc) e = hipMemcpyAsync(occluded, dOcc, n, hipMemcpyDeviceToHost, s->stream);
@@ -1005,8 +1071,8 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
     uint32_t *qCur = B.qA, *qNext = B.qB;
     for (int bounce = 0; bounce < S.maxBounces; ++bounce) {
       if ((rc = beginEvent(s, CAT_EXTEND, timing))) return rc;
-      if (count) k_extend<true><<<grid, kBlock, 0, st>>>(S, B, qCur);
-      else k_extend<false><<<grid, kBlock, 0, st>>>(S, B, qCur);
+      if (count) k_extend<true><<<persistentGrid(s, n), kBlock, 0, st>>>(S, B, qCur);
+      else k_extend<false><<<persistentGrid(s, n), kBlock, 0, st>>>(S, B, qCur);
       if ((rc = endEvent(s, timing))) return rc;
       ++launchesExtend;
       if ((rc = beginEvent(s, CAT_SHADE, timing))) return rc;
@@ -1014,7 +1080,7 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
       if ((rc = endEvent(s, timing))) return rc;
       if (S.numLights > 0) {
         if ((rc = beginEvent(s, CAT_SHADOW, timing))) return rc;
-        unsigned gridShadow = gridFor(n * S.numLights);
+        unsigned gridShadow = persistentGrid(s, n * S.numLights);
         if (count) k_shadow<true><<<gridShadow, kBlock, 0, st>>>(S, B);
         else k_shadow<false><<<gridShadow, kBlock, 0, st>>>(S, B);
         if ((rc = endEvent(s, timing))) return rc;
@@ -1054,6 +1120,10 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
     stats->raysExtend = hc.raysExtend; stats->raysShadow = hc.raysShadow;
     stats->innerExtend = hc.inner[0]; stats->primExtend = hc.prims[0];
     stats->innerShadow = hc.inner[1]; stats->primShadow = hc.prims[1];
+    stats->laneUseInnerExtend = hc.innerWaveIters[0] > 0 ? hc.inner[0] / (64.0 * hc.innerWaveIters[0]) : 0.0;
+    stats->laneUsePrimExtend = hc.primWaveIters[0] > 0 ? hc.prims[0] / (64.0 * hc.primWaveIters[0]) : 0.0;
+    stats->laneUseInnerShadow = hc.innerWaveIters[1] > 0 ? hc.inner[1] / (64.0 * hc.innerWaveIters[1]) : 0.0;
+    stats->laneUsePrimShadow = hc.primWaveIters[1] > 0 ? hc.prims[1] / (64.0 * hc.primWaveIters[1]) : 0.0;
     stats->passes = passes;
     stats->launchesExtend = launchesExtend;
     stats->launchesShadow = launchesShadow;

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Lane-utilisation probe (GPU box): counters of the traversal kernels for maxBounces = 1..4 on the bench scene."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raytracer_amd import capi  # noqa: E402
+from tools import gen_scenes  # noqa: E402
+
+d = "/tmp/rt_probe_scene"
+os.makedirs(d, exist_ok=True)
+if not os.path.exists(d + "/readme.sdml"):
+    gen_scenes.scene_readme(d, "readme", size=1080, spp=8, grid=(512, 512), texsize=512)
+hs = capi.HostScene.load(d + "/readme.sdml").build()
+dev = capi.device_scene(hs.desc)
+o = hs.desc.contents.options
+for mb in (1, 2, 4):
+    dev.set_view(options=capi.RtOptions(o.width, o.height, o.bias, o.exposure, mb, 4, o.fisheye, o.focus, o.lens))
+    dev.render(download=False)
+    _, st = dev.render(download=False)
+    _, c = dev.render(download=False, collect_counters=True)
+    print(f"maxBounces={mb}: extend {st.raysExtend / st.msExtend / 1e3:.0f} Mrays/s ({st.msExtend:.2f} ms), shadow "
+          f"{st.raysShadow / st.msShadow / 1e3:.0f} Mrays/s ({st.msShadow:.2f} ms), shade {st.msShade:.2f} ms | lane use extend inner "
+          f"{c.laneUseInnerExtend:.3f} prim {c.laneUsePrimExtend:.3f}, shadow inner {c.laneUseInnerShadow:.3f} prim {c.laneUsePrimShadow:.3f} | "
+          f"inner/ray ext {c.innerExtend / c.raysExtend:.1f} sh {c.innerShadow / c.raysShadow:.1f}, prim/ray ext {c.primExtend / c.raysExtend:.1f} sh {c.primShadow / c.raysShadow:.1f}")
