@@ -410,7 +410,7 @@ def load_device_library():
     global _device
     if _device is not None:
         return _device
-    path = os.path.join(_HERE, "libraytracer_amd.so")
+    path = os.environ.get("RT_AMD_DEVICE_LIB") or os.path.join(_HERE, "libraytracer_amd.so")  # override: kernel experiments
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: run `make hip` (or __graft_entry__.build()); there is no CPU fallback")
     _device = bind_render_abi(C.CDLL(path), "rt_")

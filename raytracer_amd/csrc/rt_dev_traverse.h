@@ -45,9 +45,7 @@ struct TravCounters {
 };
 
 // Tests object i against the ray; returns true and updates the closest hit on a strict `<` (src/acceleration/BVH.cpp:309-313).
-RT_DEV bool intersectPrim(const DevScene &S, int32_t i, V3 o, V3 nd, float &tBest, int32_t &primBest) {
-  const float4 *P = S.primHit + 3 * (int64_t)i;
-  float4 a = P[0], b = P[1], c = P[2];
+RT_DEV bool intersectPrim(const DevScene &S, float4 a, float4 b, float4 c, int32_t i, V3 o, V3 nd, float &tBest, int32_t &primBest) {
   float t;
   bool sphere = S.hasSpheres && ((__float_as_uint(a.w) | __float_as_uint(b.x) | __float_as_uint(b.y)) == 0u);
   if (!sphere) {
@@ -93,11 +91,26 @@ RT_DEV float intersectAABBFinite(V3 o, V3 inv, float mnx, float mny, float mnz, 
   return (tmax >= tmin && tmax > 0) ? tmin : kInf;
 }
 
+constexpr uint32_t kTicketChunkMax = 256, kTicketChunkMin = 64;  // a refill takes up to 64 indices: a chunk must cover one
+
 enum { TRAV_CLOSEST = 0, TRAV_ANY = 1, TRAV_POINT_LIGHT = 2 };
 
 // Scheduling thresholds of the traversal engine (lanes of one 64-lane wavefront).
-constexpr int kRefillMin = 16;  // idle lanes before the wavefront goes back to the queue
-constexpr int kFinishMin = 8;   // finished queries waiting before their results are written out
+#ifndef RT_REFILL_MIN
+#define RT_REFILL_MIN 12
+#endif
+#ifndef RT_FINISH_MIN
+#define RT_FINISH_MIN 12
+#endif
+constexpr int kRefillMin = RT_REFILL_MIN;  // idle lanes before the wavefront goes back to the queue
+constexpr int kFinishMin = RT_FINISH_MIN;   // finished queries waiting before their results are written out
+
+// Limits the host checks before a scene reaches the GPU (rt_scene_create): node and object records are addressed
+// with 32-bit byte offsets, and the per-lane stack has the reference's 64 entries (src/acceleration/BVH.cpp:10), which
+// a tree of depth <= 64 cannot overflow (near-first descent keeps at most one pending sibling per level).
+constexpr int64_t kMaxInnerNodes = (int64_t)1 << 26;      // * 64 B  < 4 GiB
+constexpr int64_t kMaxObjects = ((int64_t)1 << 32) / 48;  // * 48 B  < 4 GiB
+constexpr int kMaxTreeDepth = kMaxStack;
 
 // Traversal engine. Every wavefront pulls queries from a queue (one atomic per refill) and traces one query per lane.
 // Each lane always has exactly one pending operation:
@@ -128,15 +141,16 @@ constexpr int kFinishMin = 8;   // finished queries waiting before their results
 //   uint32_t fetch(uint32_t idx, V3 &o, V3 &d, int &mode, float &bulbDist) load query idx, return a tag for store()
 //   void store(uint32_t tag, HitRec hit, bool occluded, V3 o, V3 nd)       deliver its result
 template <class Source, bool RUNTIME_MODE, bool COUNT, int K, int BLOCK>
-RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint2 *ldsStack, TravCounters &tc,
-                          bool &stackOverflow) {
+RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint2 *ldsStack, TravCounters &tc) {
   static_assert((K & (K - 1)) == 0, "K must be a power of two");
   const uint32_t total = src.total();
-  const int col = threadIdx.x;  // this lane's column of the LDS stack array
   const uint32_t laneId = __lane_id();
+  const char *nodeBase = reinterpret_cast<const char *>(S.nodes);
+  const char *primBase = reinterpret_cast<const char *>(S.primHit);
   // Per-lane stack: entries [lo, sp) live in LDS (slot = index % K; entry slot s of lane l is ldsStack[s * BLOCK + l],
   // so lanes never share a bank), entries [0, lo) have been spilled to per-lane scratch. sp/lo are registers; only
   // the spill array is addressed dynamically.
+  uint2 *stackCol = ldsStack + threadIdx.x;
   uint2 spill[kMaxStack - K];
   enum { OP_IDLE = 0, OP_INNER = 1, OP_PRIM = 2, OP_FINISH = 3, OP_FINISH_EARLY = 4 };
   int op = OP_IDLE;
@@ -145,122 +159,147 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
   float tBest = kInf, bulbDist = 0.0f;
   int32_t primBest = -1, cur = 0, pi = 0, pe = 0;
   int sp = 0, lo = 0, mode = TRAV_CLOSEST;
-  bool finite = false;
+  bool finite = true;
   bool exhausted = false;  // wave-uniform: the queue has no more queries
+  uint32_t chunkPos = 0, chunkEnd = 0;
+  // chunk size: about 16 chunks per wavefront of the grid, so the last chunks do not leave most of the GPU idle
+  const uint32_t kTicketChunk = min(kTicketChunkMax, max(kTicketChunkMin, total / (gridDim.x * (BLOCK / 64) * 16u)));
+  bool waveExact = false;  // wave-uniform: some lane holds a ray the min/max slab test is not valid for
 
   while (true) {
     bool needPop = false, haveNext = false;
     int32_t next = 0;
-    unsigned long long mInner = __ballot(op == OP_INNER), mPrim = __ballot(op == OP_PRIM);
-    unsigned long long mFinish = __ballot(op >= OP_FINISH), mIdle = __ballot(op == OP_IDLE);
-    int nInner = __popcll(mInner), nPrim = __popcll(mPrim), nFinish = __popcll(mFinish), nIdle = __popcll(mIdle);
-
-    if (nFinish > 0 && (nFinish >= kFinishMin || nInner + nPrim == 0)) {
-      // ---------------------------------------------------------------- FINISH: planes, result, lane becomes idle
-      if (op >= OP_FINISH) {
-        bool occluded = op == OP_FINISH_EARLY;
-        if (op == OP_FINISH) {
-          for (int32_t k = 0; k < S.numPlanes; ++k) {
-            // Plane::intersect, src/scene/Object.cpp:133-141; planes lose ties to BVH objects (raytracer.cpp:192)
-            if (COUNT) ++tc.planes;
-            const DevPlane &pl = S.planes[k];
-            V3 pn = v3(pl.normal), pp = v3(pl.point);
-            float t = dot(pp - o, pn) / dot(nd, pn);
-            if (t < 0) continue;
-            if (t < tBest) {
-              tBest = t; primBest = S.numPrims + k;
-              if (RUNTIME_MODE && mode == TRAV_ANY) break;
+    const unsigned long long mInner = __ballot(op == OP_INNER), mPrim = __ballot(op == OP_PRIM);
+    const int nInner = __popcll(mInner), nPrim = __popcll(mPrim);
+    const int nOther = 64 - nInner - nPrim;  // finished + idle lanes
+    bool special = false;
+    if (nOther >= kFinishMin || nInner + nPrim == 0) {
+      const unsigned long long mFinish = __ballot(op >= OP_FINISH);
+      const int nFinish = __popcll(mFinish), nIdle = nOther - nFinish;
+      if (nFinish > 0 && (nFinish >= kFinishMin || nInner + nPrim == 0)) {
+        // -------------------------------------------------------------- FINISH: planes, result, lane becomes idle
+        special = true;
+        if (op >= OP_FINISH) {
+          bool occluded = op == OP_FINISH_EARLY;
+          if (op == OP_FINISH) {
+            for (int32_t k = 0; k < S.numPlanes; ++k) {
+              // Plane::intersect, src/scene/Object.cpp:133-141; planes lose ties to BVH objects (raytracer.cpp:192)
+              if (COUNT) ++tc.planes;
+              const DevPlane &pl = S.planes[k];
+              V3 pn = v3(pl.normal), pp = v3(pl.point);
+              float t = dot(pp - o, pn) / dot(nd, pn);
+              if (t < 0) continue;
+              if (t < tBest) {
+                tBest = t; primBest = S.numPrims + k;
+                if (RUNTIME_MODE && mode == TRAV_ANY) break;
+              }
+            }
+            if (RUNTIME_MODE && mode == TRAV_POINT_LIGHT) {
+              // object hits were checked when they were accepted; only a plane can still satisfy the predicate
+              if (primBest >= S.numPrims) {
+                V3 hp = tBest * nd + o;
+                occluded = magnitude(o - hp) < bulbDist;
+              }
+            } else {
+              occluded = primBest >= 0;
             }
           }
-          if (RUNTIME_MODE && mode == TRAV_POINT_LIGHT) {
-            // object hits were checked when they were accepted; only a plane can still satisfy the predicate
-            if (primBest >= S.numPrims) {
-              V3 hp = tBest * nd + o;
-              occluded = magnitude(o - hp) < bulbDist;
-            }
-          } else {
-            occluded = primBest >= 0;
-          }
+          HitRec h;
+          h.t = primBest >= 0 ? tBest : kInf;
+          h.prim = primBest;
+          src.store(item, h, occluded, o, nd);
+          op = OP_IDLE;
+          finite = true;
         }
-        HitRec h;
-        h.t = primBest >= 0 ? tBest : kInf;
-        h.prim = primBest;
-        src.store(item, h, occluded, o, nd);
-        op = OP_IDLE;
-      }
-    } else if (!exhausted && nIdle >= kRefillMin) {
-      // ---------------------------------------------------------------- REFILL idle lanes from the queue
-      int leader = __ffsll((long long)mIdle) - 1;
-      uint32_t base = 0;
-      if ((int)laneId == leader) base = atomicAdd(ticket, (uint32_t)nIdle);
-      base = __shfl(base, leader);
-      exhausted = base + (uint32_t)nIdle >= total;
-      uint32_t idx = base + (uint32_t)__popcll(mIdle & ((1ull << laneId) - 1ull));
-      if (op == OP_IDLE && idx < total) {
-        V3 d;
-        item = src.fetch(idx, o, d, mode, bulbDist);
-        nd = normalized(d);
-        tBest = kInf; primBest = -1; sp = 0; lo = 0;
-        op = OP_FINISH;
-        if (S.rootRef != kNoBvh) {
-          inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // src/acceleration/BVH.cpp:293
-          finite = S.boxesFinite && isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z) && inv.x != 0 && inv.y != 0 &&
-                   inv.z != 0 && isfinite(o.x) && isfinite(o.y) && isfinite(o.z);
-          float rootDist = intersectAABB(o, inv, S.rootMin[0], S.rootMin[1], S.rootMin[2], S.rootMax[0], S.rootMax[1], S.rootMax[2]);
-          if (rootDist < kInf) { next = S.rootRef; haveNext = true; }
-        }
-      }
-    } else if (nInner + nPrim == 0) {
-      break;  // nothing pending, nothing to finish, queue exhausted (or fewer idle lanes than a refill needs: none hold work)
-    } else if (nInner >= nPrim) {
-      // ---------------------------------------------------------------- INNER: both child boxes of the current node
-      if (op == OP_INNER) {
-        if (COUNT) { ++tc.inner; tc.innerWaveIters += 1.0f / (float)nInner; }
-        const float4 *N = S.nodes + 4 * (int64_t)cur;
-        float4 a = N[0], b = N[1], c = N[2];
-        int4 r = reinterpret_cast<const int4 *>(N)[3];
-        float dl, dr;
-        if (finite) {
-          dl = intersectAABBFinite(o, inv, a.x, a.y, a.z, a.w, b.x, b.y);
-          dr = intersectAABBFinite(o, inv, b.z, b.w, c.x, c.y, c.z, c.w);
+        waveExact = __ballot(!finite) != 0ull;
+      } else if (!exhausted && nIdle >= kRefillMin) {
+        // -------------------------------------------------------------- REFILL idle lanes from the queue
+        special = true;
+        const unsigned long long mIdle = __ballot(op == OP_IDLE);
+        int leader = __ffsll((long long)mIdle) - 1;
+        // Queue indices come from a wave-local chunk [chunkPos, chunkEnd); one atomic on the shared counter buys
+        // kTicketChunk of them, so the counter (a single address all wavefronts hit) sees few operations.
+        const uint32_t avail = chunkEnd - chunkPos, want = (uint32_t)nIdle;
+        const uint32_t rank = (uint32_t)__popcll(mIdle & ((1ull << laneId) - 1ull));
+        uint32_t idx = chunkPos + rank;
+        if (avail < want) {
+          uint32_t base = 0;
+          if ((int)laneId == leader) base = atomicAdd(ticket, kTicketChunk);
+          base = __shfl(base, leader);
+          if (rank >= avail) idx = base + (rank - avail);
+          chunkPos = base + (want - avail);
+          chunkEnd = base + kTicketChunk;
+          if (base >= total) { exhausted = true; chunkPos = chunkEnd = 0; }
         } else {
-          dl = intersectAABB(o, inv, a.x, a.y, a.z, a.w, b.x, b.y);
-          dr = intersectAABB(o, inv, b.z, b.w, c.x, c.y, c.z, c.w);
+          chunkPos += want;
         }
-        // Near child first, right only if strictly nearer (src/acceleration/BVH.cpp:322-333); a child that cannot
-        // beat the closest hit any more is dropped here instead of at pop time.
-        bool hl = dl < tBest, hr = dr < tBest;
-        bool both = hl && hr;
-        bool swap = both && dr < dl;
-        if (both) {
-          if (sp == kMaxStack) {
-            stackOverflow = true;  // the reference would write past its arrays here
+        if (op == OP_IDLE && idx < total) {
+          V3 d;
+          item = src.fetch(idx, o, d, mode, bulbDist);
+          nd = normalized(d);
+          tBest = kInf; primBest = -1; sp = 0; lo = 0;
+          op = OP_FINISH;
+          if (S.rootRef != kNoBvh) {
+            inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // src/acceleration/BVH.cpp:293
+            finite = S.boxesFinite && isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z) && inv.x != 0 && inv.y != 0 &&
+                     inv.z != 0 && isfinite(o.x) && isfinite(o.y) && isfinite(o.z);
+            float rootDist = intersectAABB(o, inv, S.rootMin[0], S.rootMin[1], S.rootMin[2], S.rootMax[0], S.rootMax[1], S.rootMax[2]);
+            if (rootDist < kInf) { next = S.rootRef; haveNext = true; }
+          }
+        }
+        waveExact = __ballot(!finite) != 0ull;
+      } else if (nInner + nPrim == 0) {
+        break;  // every lane idle and the queue exhausted
+      }
+    }
+    if (!special) {
+      if (nInner >= nPrim) {
+        // -------------------------------------------------------------- INNER: both child boxes of the current node
+        if (op == OP_INNER) {
+          if (COUNT) { ++tc.inner; tc.innerWaveIters += 1.0f / (float)nInner; }
+          const float4 *N = reinterpret_cast<const float4 *>(nodeBase + ((uint32_t)cur << 6));
+          float4 a = N[0], b = N[1], c = N[2];
+          int4 r = reinterpret_cast<const int4 *>(N)[3];
+          float dl, dr;
+          if (waveExact) {  // wave-uniform: the compare-and-select form is valid for every ray, just slower
+            dl = intersectAABB(o, inv, a.x, a.y, a.z, a.w, b.x, b.y);
+            dr = intersectAABB(o, inv, b.z, b.w, c.x, c.y, c.z, c.w);
           } else {
-            if (sp - lo == K) { spill[lo] = ldsStack[(lo & (K - 1)) * BLOCK + col]; ++lo; }
-            ldsStack[(sp & (K - 1)) * BLOCK + col] = make_uint2(__float_as_uint(swap ? dl : dr), (uint32_t)(swap ? r.x : r.y));
+            dl = intersectAABBFinite(o, inv, a.x, a.y, a.z, a.w, b.x, b.y);
+            dr = intersectAABBFinite(o, inv, b.z, b.w, c.x, c.y, c.z, c.w);
+          }
+          // Near child first, right only if strictly nearer (src/acceleration/BVH.cpp:322-333); a child that cannot
+          // beat the closest hit any more is dropped here instead of at pop time.
+          bool hl = dl < tBest, hr = dr < tBest;
+          bool both = hl && hr;
+          bool swap = both && dr < dl;
+          if (both) {
+            if (sp - lo == K) { spill[lo] = stackCol[(lo & (K - 1)) * BLOCK]; ++lo; }
+            stackCol[(sp & (K - 1)) * BLOCK] = make_uint2(__float_as_uint(swap ? dl : dr), (uint32_t)(swap ? r.x : r.y));
             ++sp;
           }
+          next = (hl && !swap) ? r.x : r.y;
+          haveNext = hl || hr;
+          needPop = !haveNext;
         }
-        next = (hl && !swap) ? r.x : r.y;
-        haveNext = hl || hr;
-        needPop = !haveNext;
-      }
-    } else {
-      // ---------------------------------------------------------------- PRIM: one object of the current leaf
-      if (op == OP_PRIM) {
-        if (COUNT) { ++tc.prims; tc.primWaveIters += 1.0f / (float)nPrim; }
-        bool accepted = intersectPrim(S, pi, o, nd, tBest, primBest);
-        ++pi;
-        if (RUNTIME_MODE && accepted && mode != TRAV_CLOSEST) {
-          if (mode == TRAV_ANY) {
-            op = OP_FINISH_EARLY;
-          } else {
-            // |point - info.point| < |center - point| with info.point = t * nd + origin (src/scene/Object.cpp:22-24)
-            V3 hp = tBest * nd + o;
-            if (magnitude(o - hp) < bulbDist) op = OP_FINISH_EARLY;
+      } else {
+        // -------------------------------------------------------------- PRIM: one object of the current leaf
+        if (op == OP_PRIM) {
+          if (COUNT) { ++tc.prims; tc.primWaveIters += 1.0f / (float)nPrim; }
+          const float4 *P = reinterpret_cast<const float4 *>(primBase + (uint32_t)pi * 48u);
+          bool accepted = intersectPrim(S, P[0], P[1], P[2], pi, o, nd, tBest, primBest);
+          ++pi;
+          if (RUNTIME_MODE && accepted && mode != TRAV_CLOSEST) {
+            if (mode == TRAV_ANY) {
+              op = OP_FINISH_EARLY;
+            } else {
+              // |point - info.point| < |center - point| with info.point = t * nd + origin (src/scene/Object.cpp:22-24)
+              V3 hp = tBest * nd + o;
+              if (magnitude(o - hp) < bulbDist) op = OP_FINISH_EARLY;
+            }
           }
+          needPop = op == OP_PRIM && pi == pe;
         }
-        needPop = op == OP_PRIM && pi == pe;
       }
     }
     // ------------------------------------------------------------------ common tail: next node of lanes that need one
@@ -272,7 +311,7 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
         // A spilled entry is first copied back into its LDS slot (rare), so that the read below is always a plain LDS
         // read of one address; reading "LDS or spill" directly makes the compiler select between the two addresses
         // and issue a generic (flat) load.
-        uint2 *slot = ldsStack + (sp & (K - 1)) * BLOCK + col;
+        uint2 *slot = stackCol + (sp & (K - 1)) * BLOCK;
         if (sp < lo) { lo = sp; *slot = spill[sp]; }
         uint2 e = *slot;
         if (__uint_as_float(e.x) < tBest) { next = (int32_t)e.y; haveNext = true; break; }

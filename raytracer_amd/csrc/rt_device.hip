@@ -71,7 +71,7 @@ RT_DEV uint32_t queueSlot(uint32_t *counter, bool pred) {
 }
 
 template <bool COUNT>
-RT_DEV void flushCounters(Counts *c, const TravCounters &tc, bool overflow, int kind) {
+RT_DEV void flushCounters(Counts *c, const TravCounters &tc, int kind) {
   if (COUNT) {
     // wave reduction, then one atomic per wavefront and counter
     unsigned long long a = tc.inner, b = tc.prims, p = tc.planes;
@@ -85,7 +85,6 @@ RT_DEV void flushCounters(Counts *c, const TravCounters &tc, bool overflow, int 
       atomicAdd(&c->innerWaveIters[kind], wi); atomicAdd(&c->primWaveIters[kind], wp);
     }
   }
-  if (overflow) atomicOr(&c->stackOverflow, 1u);
 }
 
 RT_DEV float getRayScaleX(float x, int w, int h) { return (2 * x - w) / max(w, h); }  // src/scene/raytracer.cpp:13-15
@@ -159,10 +158,9 @@ template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_extend(DevScene S, PathBuf B, const uint32_t *queue) {
   __shared__ uint2 ldsStack[kStackLds * kBlock];
   TravCounters tc = {0, 0, 0, 0.0f, 0.0f};
-  bool overflow = false;
   ExtendSource src{B, queue};
-  traverseQueue<ExtendSource, false, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[0], ldsStack, tc, overflow);
-  flushCounters<COUNT>(B.counts, tc, overflow, 0);
+  traverseQueue<ExtendSource, false, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[0], ldsStack, tc);
+  flushCounters<COUNT>(B.counts, tc, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------- k_shade
@@ -308,10 +306,9 @@ template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_shadow(DevScene S, PathBuf B) {
   __shared__ uint2 ldsStack[kStackLds * kBlock];
   TravCounters tc = {0, 0, 0, 0.0f, 0.0f};
-  bool overflow = false;
   ShadowSource src{S, B, B.counts->nHit};
-  traverseQueue<ShadowSource, true, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[1], ldsStack, tc, overflow);
-  flushCounters<COUNT>(B.counts, tc, overflow, 1);
+  traverseQueue<ShadowSource, true, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[1], ldsStack, tc);
+  flushCounters<COUNT>(B.counts, tc, 1);
 }
 
 // L += beta * (getColor(point) * sum over lights, in scene order) — src/scene/raytracer.cpp:198-206, 231
@@ -443,10 +440,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_primary(DevScene S, int32_t x0
                                                           int32_t *outPrim, float *outT, Counts *counts) {
   __shared__ uint2 ldsStack[kStackLds * kBlock];
   TravCounters tc = {0, 0, 0, 0.0f, 0.0f};
-  bool overflow = false;
   PrimarySource src{S, x0, y0, w, h, outPrim, outT};
-  traverseQueue<PrimarySource, false, false, kStackLds, kBlock>(S, src, &counts->ticket[2], ldsStack, tc, overflow);
-  flushCounters<false>(counts, tc, overflow, 0);
+  traverseQueue<PrimarySource, false, false, kStackLds, kBlock>(S, src, &counts->ticket[2], ldsStack, tc);
+  flushCounters<false>(counts, tc, 0);
 }
 
 template <bool ANY>
@@ -498,10 +494,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene S, int64_t n, co
                                                        uint8_t *outOccluded, Counts *counts) {
   __shared__ uint2 ldsStack[kStackLds * kBlock];
   TravCounters tc = {0, 0, 0, 0.0f, 0.0f};
-  bool overflow = false;
   RaysSource<ANY> src{S, n, origins, directions, outPrim, outT, outPoint, outNormal, outOccluded};
-  traverseQueue<RaysSource<ANY>, ANY, false, kStackLds, kBlock>(S, src, &counts->ticket[2], ldsStack, tc, overflow);
-  flushCounters<false>(counts, tc, overflow, 0);
+  traverseQueue<RaysSource<ANY>, ANY, false, kStackLds, kBlock>(S, src, &counts->ticket[2], ldsStack, tc);
+  flushCounters<false>(counts, tc, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------- host side
@@ -533,6 +528,7 @@ struct RtScene {
   std::vector<void *> allocs;
   int32_t numPointLights = 0, numAnyLights = 0, numEnvLights = 0;
   int numCUs = 256;
+  int blocksPerCU = 4;  // resident blocks of a traversal kernel per CU (occupancy query at scene creation)
   // render state (allocated on first use, grown when needed)
   PathBuf buf{};
   void *arena = nullptr;
@@ -694,6 +690,22 @@ int buildScene(RtScene *s, const RtSceneDesc *d) {
     std::memcpy(&N[3], refs, 16);
   }
   if (bigLeaves.size() >= (1u << 24)) return failMsg(RT_ERR_INVALID, "too many oversized BVH leaves");
+  if (numInner >= kMaxInnerNodes) return failMsg(RT_ERR_INVALID, "BVH has more inner nodes than 32-bit record offsets address");
+  if (d->numPrims >= kMaxObjects) return failMsg(RT_ERR_INVALID, "more objects than 32-bit record offsets address");
+  {
+    // The traversal stack has the reference's 64 entries and, unlike the reference, no way to write past them: refuse
+    // trees deeper than that before they reach the GPU.
+    int maxDepth = 0;
+    std::vector<std::pair<int32_t, int>> walk;
+    if (d->numNodes > 0) walk.push_back({0, 1});
+    while (!walk.empty()) {
+      auto [node, depth] = walk.back();
+      walk.pop_back();
+      maxDepth = std::max(maxDepth, depth);
+      if (d->nodes[node].numObjects <= 0) { walk.push_back({node + 1, depth + 1}); walk.push_back({d->nodes[node].rightOrStart, depth + 1}); }
+    }
+    if (maxDepth > kMaxTreeDepth) return failMsg(RT_ERR_INVALID, "BVH deeper than the 64-entry traversal stack (depth " + std::to_string(maxDepth) + ")");
+  }
   if (d->numNodes > 0) {
     dev.rootRef = childRef(0);
     std::memcpy(dev.rootMin, d->nodes[0].aabbMin, 12);
@@ -888,7 +900,7 @@ inline unsigned gridFor(int64_t n) { return (unsigned)std::max<int64_t>(1, (n + 
 // Traversal kernels are persistent: enough blocks to fill every CU once (8 blocks of 4 wavefronts = the 32-wave limit),
 // fewer when the queue cannot feed them.
 inline unsigned persistentGrid(const RtScene *s, int64_t n) {
-  return (unsigned)std::min<int64_t>(gridFor(n), (int64_t)s->numCUs * 8);
+  return (unsigned)std::min<int64_t>(gridFor(n), (int64_t)s->numCUs * s->blocksPerCU);
 }
 
 }  // namespace
@@ -909,6 +921,10 @@ RtScene *rt_scene_create(const RtSceneDesc *desc, int device) {
   s->device = device;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->numCUs = prop.multiProcessorCount;
+  {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_shadow<false>, kBlock, 0) == hipSuccess && nb > 0) s->blocksPerCU = nb;
+  }
   if ((e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)) != hipSuccess) {
     g_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
     return nullptr;
@@ -1108,7 +1124,6 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
   Counts hc{};
   HIP_TRY(hipMemcpyAsync(&hc, s->counts, sizeof(Counts), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  if (hc.stackOverflow) return failMsg(RT_ERR_INVALID, "BVH traversal stack overflow (tree deeper than 64 pending nodes)");
   if (stats) {
     std::memset(stats, 0, sizeof *stats);
     stats->cameraSamples = hc.samples;

@@ -15,8 +15,8 @@ if not os.path.exists(d + "/readme.sdml"):
 hs = capi.HostScene.load(d + "/readme.sdml").build()
 dev = capi.device_scene(hs.desc)
 o = hs.desc.contents.options
-for mb in (1, 2, 4):
-    dev.set_view(options=capi.RtOptions(o.width, o.height, o.bias, o.exposure, mb, 4, o.fisheye, o.focus, o.lens))
+for mb in [int(x) for x in os.environ.get('PROBE_BOUNCES', '1,2,4').split(',')]:
+    dev.set_view(options=capi.RtOptions(o.width, o.height, o.bias, o.exposure, mb, 7, o.fisheye, o.focus, o.lens))
     dev.render(download=False)
     _, st = dev.render(download=False)
     _, c = dev.render(download=False, collect_counters=True)
