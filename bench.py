@@ -80,7 +80,7 @@ def main():
         if world > 1:
             dist.barrier()
 
-    from raytracer_amd import capi
+    from raytracer_amd import capi, multi_gpu
 
     t_setup = time.time()
     path = scene_files(args, rank, barrier)
@@ -93,11 +93,8 @@ def main():
     setup_s = time.time() - t_setup
 
     def step():
-        _, st = dev.render(seed=56, part_index=rank, part_count=world, tile=(args.tile, args.tile),
-                           samples_per_pass=args.spp_pass, out_ptr=out.data_ptr())
-        if world > 1:
-            dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
-        return st
+        return multi_gpu.render_frame(dev, out, rank, world, tile=(args.tile, args.tile), seed=56,
+                                      samples_per_pass=args.spp_pass)
 
     for _ in range(args.warmup):
         step()
@@ -194,7 +191,7 @@ def main():
         "rays_per_frame": int(rays_total / args.steps),
         "rays_per_camera_sample": round(rays_total / max(1.0, samples_total), 3),
         "kernel_ms_per_frame": {k: round(sum(getattr(s, k) for s in stats) / args.steps, 2)
-                                for k in ("msTotal", "msRaygen", "msExtend", "msShade", "msShadow", "msAccumulate", "msResolve")},
+                                for k in ("msTotal", "msRaygen", "msExtend", "msShade", "msShadow", "msDirect", "msAccumulate", "msResolve")},
         "setup_s": round(setup_s, 1),
         "roofline": roofline,
         "cpu_baseline": cpu,

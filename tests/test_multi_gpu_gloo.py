@@ -1,0 +1,71 @@
+"""The N > 1 path on CPU: two processes (gloo), each renders its image tiles, rank 0 gathers. The renderer behind the
+C ABI here is the CPU restatement (tests may use it); partition, gather and the rank-count independence of the result
+are the product's host logic in raytracer_amd/multi_gpu.py, the same code bench.py runs over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from raytracer_amd import capi, multi_gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, scene_file, tile, result_path):
+    from tests.oracle_binding import oracle_scene
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        hs = capi.HostScene.load(scene_file).build()
+        o = hs.desc.contents.options
+        scene = oracle_scene(hs.desc, threads=2)
+        out = torch.zeros((o.height, o.width, 4), dtype=torch.float32)
+        st = multi_gpu.render_partition(scene, out, rank, world, tile=tile, seed=7)
+        own = multi_gpu.tile_owner(o.width, o.height, tile, world) == rank
+        mine = out.numpy().copy()
+        assert np.all(mine[~own] == 0), "pixels outside this rank's tiles must be exact zeros"
+        assert st.cameraSamples == int(own.sum()) * o.numRays
+        multi_gpu.gather_frame(out, world)
+        samples = torch.tensor([float(st.cameraSamples)], dtype=torch.float64)
+        dist.all_reduce(samples)
+        if rank == 0:
+            np.savez(result_path, frame=out.numpy(), samples=samples.numpy())
+        scene.close()
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scene_name,tile", [("mesh1k_gi", (32, 32)), ("spheres_txt", (16, 8))])
+def test_two_ranks_equal_one(tmp_path, scene_path, scene_name, tile):
+    from tests.oracle_binding import oracle_scene
+    scene_file = scene_path(scene_name)
+    result = str(tmp_path / "gathered.npz")
+    mp.spawn(_worker, args=(2, _free_port(), scene_file, tile, result), nprocs=2, join=True)
+    got = np.load(result)
+    hs = capi.HostScene.load(scene_file).build()
+    o = hs.desc.contents.options
+    whole = oracle_scene(hs.desc, threads=4)
+    ref, st = whole.render(seed=7)
+    whole.close()
+    ref = np.asarray(ref, dtype=np.float32).reshape(o.height, o.width, 4)
+    assert int(got["samples"][0]) == st.cameraSamples
+    assert np.array_equal(got["frame"], ref), "the gathered two-rank frame must equal the one-rank frame bit for bit"
+
+
+def test_tile_owner_matches_library_rule():
+    own = multi_gpu.tile_owner(70, 50, (32, 32), 3)
+    assert own.shape == (50, 70)
+    assert own[0, 0] == 0 and own[0, 32] == 1 and own[0, 64] == 2 and own[32, 0] == 0 and own[32, 32] == 1
+    assert np.all(multi_gpu.tile_owner(9, 9, (4, 4), 1) == 0)
