@@ -7,7 +7,7 @@ pixel, ~1.05 M triangles + 2 textured spheres + 3 textured planes, point + envir
 
 A step is one whole frame through the C ABI (rt_render): scene and BVH already resident in HBM, the frame left in a
 device buffer. With N > 1 every rank renders its interleaved 32x32 tiles of the SAME frame (total work fixed: strong
-scaling) and the tiles are combined on rank 0 by an RCCL reduce over xGMI (pixels outside a rank's tiles are exactly 0).
+scaling) and every rank's own pixels are gathered to rank 0 over RCCL/xGMI (one gather per frame, 1/N of the frame per rank).
 "ray" = one BVH traversal query (Scene::findClosestObject / findAnyObject in the reference): camera, bounce and shadow
 rays alike. Rank 0 prints ONE JSON line.
 """
@@ -92,8 +92,10 @@ def main():
     out = torch.zeros((H, W, 4), dtype=torch.float32, device=torch.device("cuda", local_rank))
     setup_s = time.time() - t_setup
 
+    gatherer = multi_gpu.TileGather(W, H, (args.tile, args.tile), rank, world, out.device)
+
     def step():
-        return multi_gpu.render_frame(dev, out, rank, world, tile=(args.tile, args.tile), seed=56,
+        return multi_gpu.render_frame(dev, out, rank, world, gatherer=gatherer, tile=(args.tile, args.tile), seed=56,
                                       samples_per_pass=args.spp_pass)
 
     for _ in range(args.warmup):
@@ -185,7 +187,7 @@ def main():
         "config": {"workload": f"README-scene stand-in: {W}x{H}, {o.numRays} spp, {tris} BVH objects + {d.numPlanes} planes, "
                                f"point + environment light, maxBounces {o.maxBounces}",
                    "width": W, "height": H, "spp": o.numRays, "objects": tris, "bvh_nodes": int(d.numNodes),
-                   "parallelism": f"image tiles {args.tile}x{args.tile} interleaved over {world} GPU(s), RCCL reduce to rank 0"},
+                   "parallelism": f"image tiles {args.tile}x{args.tile} interleaved over {world} GPU(s), RCCL gather to rank 0"},
         "wall_time_s": round(ms_per_step / 1e3, 3),
         "camera_msamples_per_s": round(samples_total / elapsed / 1e6, 2),
         "rays_per_frame": int(rays_total / args.steps),

@@ -4,9 +4,9 @@ the whole frame.
 The reference splits a frame over worker threads by pixel index (src/scene/raytracer.cpp:258, 290-299); here the unit is
 a tile of pixels and the workers are GPUs. The scene and its BVH are replicated per GPU (they are read-only and small
 next to 288 GB of HBM), a pixel's random stream depends only on (seed, pixel, sample), and pixels outside a rank's tiles
-come back as exact zeros, so the partial frames combine by addition into a frame that does not depend on the number of
-ranks. The only exchange is that one reduce of width*height*4 floats per frame (RCCL over xGMI with the "nccl" backend,
-plain TCP loopback with "gloo").
+come back as exact zeros, so the frame does not depend on the number of ranks. The only exchange is one gather per frame
+of each rank's own pixels (width*height*16/world bytes per rank) to rank 0: RCCL over xGMI with the "nccl" backend, TCP
+loopback with "gloo".
 """
 import numpy as np
 
@@ -30,15 +30,46 @@ def render_partition(scene, out, rank, world, tile=(32, 32), seed=56, samples_pe
     return st
 
 
-def gather_frame(out, world, dst=0):
-    """Combines the ranks' partial frames on rank `dst` (in place). No-op for a single rank."""
-    if world > 1:
+class TileGather:
+    """Moves every rank's own pixels to rank 0: each rank packs the pixels of its tiles (1/world of the frame, 16 B per
+    pixel) into one contiguous buffer, one gather brings the buffers to rank 0 (point-to-point transfers into rank 0,
+    no ring), rank 0 writes them to their places in its frame. Nothing is added, so the gathered frame holds exactly
+    the bits each rank rendered."""
+
+    def __init__(self, width, height, tile, rank, world, device):
+        import torch
+        self.rank, self.world = rank, world
+        owner = tile_owner(width, height, tile, world).reshape(-1)
+        counts = np.bincount(owner, minlength=world)
+        self.max_pixels = int(counts.max())
+        ranks = range(world) if rank == 0 else [rank]
+        self.index = {r: torch.from_numpy(np.flatnonzero(owner == r)).to(device) for r in ranks}
+        self.packed = torch.zeros((self.max_pixels, 4), dtype=torch.float32, device=device)
+        self.inbox = ([torch.zeros_like(self.packed) for _ in range(world)] if rank == 0 and world > 1 else None)
+
+    def gather(self, out, dst=0):
+        if self.world <= 1:
+            return out
         import torch.distributed as dist
-        dist.reduce(out, dst=dst, op=dist.ReduceOp.SUM)
-    return out
+        if dst != 0:
+            raise ValueError("the frame is gathered on rank 0")
+        flat = out.view(-1, 4)
+        mine = self.index[self.rank]
+        self.packed[: mine.numel()] = flat[mine]
+        dist.gather(self.packed, self.inbox, dst=0)
+        if self.rank == 0:
+            for r in range(1, self.world):
+                idx = self.index[r]
+                flat[idx] = self.inbox[r][: idx.numel()]
+        return out
 
 
-def render_frame(scene, out, rank, world, **kw):
-    st = render_partition(scene, out, rank, world, **kw)
-    gather_frame(out, world)
+def render_frame(scene, out, rank, world, gatherer=None, tile=(32, 32), **kw):
+    """One frame: this rank's tiles, then the gather. `gatherer` is the TileGather of this (size, tile, world); pass it
+    to keep its buffers across frames."""
+    st = render_partition(scene, out, rank, world, tile=tile, **kw)
+    if world > 1:
+        if gatherer is None:
+            gatherer = TileGather(out.shape[1], out.shape[0], tile, rank, world, out.device)
+        gatherer.gather(out)
     return st

@@ -36,7 +36,7 @@ def _worker(rank, world, port, scene_file, tile, result_path):
         mine = out.numpy().copy()
         assert np.all(mine[~own] == 0), "pixels outside this rank's tiles must be exact zeros"
         assert st.cameraSamples == int(own.sum()) * o.numRays
-        multi_gpu.gather_frame(out, world)
+        multi_gpu.TileGather(o.width, o.height, tile, rank, world, out.device).gather(out)
         samples = torch.tensor([float(st.cameraSamples)], dtype=torch.float64)
         dist.all_reduce(samples)
         if rank == 0:
