@@ -234,7 +234,16 @@ RT_DEV RGBA texel(const DevScene &S, int32_t tex, float row, float col) {
 }
 
 // Object::getColor overrides, src/scene/Object.cpp:101-109 (sphere), :143-158 (plane), :215-224 (triangle)
-RT_DEV RGBA getColor(const DevScene &S, int32_t prim, V3 ip) {
+// What shading reads of the object that was hit, loaded in one batch right after the hit is known (one memory round
+// trip instead of one per use).
+struct ObjectData {
+  float4 a, b, c;   // hit record: triangle p1, normal, e1, e2 / sphere center, r
+  float4 color;     // Object::color
+  int32_t texture;  // -1 = none
+  int32_t material;
+};
+
+RT_DEV RGBA getColor(const DevScene &S, int32_t prim, V3 ip, const ObjectData &od) {
   if (prim >= S.numPrims) {
     const DevPlane &p = S.planes[prim - S.numPrims];
     if (p.texture < 0) return rgba(p.color[0], p.color[1], p.color[2], p.color[3]);
@@ -251,10 +260,9 @@ RT_DEV RGBA getColor(const DevScene &S, int32_t prim, V3 ip) {
     y = clampf(height - y, 0, height - 1);
     return texel(S, p.texture, y, x);
   }
-  int32_t ti = S.primTexture[prim];
-  if (ti < 0) return rgba(S.primColor[prim]);
-  const float4 *P = S.primHit + 3 * (int64_t)prim;
-  float4 a = P[0], b = P[1], c = P[2];
+  int32_t ti = od.texture;
+  if (ti < 0) return rgba(od.color);
+  float4 a = od.a, b = od.b, c = od.c;
   bool sphere = (__float_as_uint(a.w) | __float_as_uint(b.x) | __float_as_uint(b.y)) == 0u;
   if (sphere) {
     DevTexture tex = S.textures[ti];

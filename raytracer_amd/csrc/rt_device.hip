@@ -36,10 +36,17 @@ namespace {
 constexpr int kBlock = 256;       // 4 wavefronts
 constexpr int kStackLds = 8;      // stack entries per lane kept in LDS (8 B each -> 16 KiB per block)
 
+// Every group of fields that one kernel updates with atomics while others only read sits in a 128-byte line of its own:
+// a read of a line that thousands of wavefronts are adding to queues behind those adds.
+struct Ticket {
+  alignas(128) uint32_t next;  // next unclaimed queue index
+};
 struct Counts {
-  uint32_t nActive, nNext, nHit, stackOverflow;
-  uint32_t ticket[4];  // next unclaimed queue index: [0] path extension, [1] light visibility, [2] trace-only kernels
-  unsigned long long raysClosest, raysAny, samples, raysExtend, raysShadow;
+  alignas(128) uint32_t nActive;  // live paths of this bounce (written between kernels, and by k_raygen for fisheye)
+  alignas(128) uint32_t nHit;     // appended by k_shade; {nHit, nNext} are added to as ONE 64-bit word
+  uint32_t nNext;
+  Ticket ticket[3];               // [0] path extension, [1] light visibility, [2] trace-only kernels
+  alignas(128) unsigned long long raysClosest, raysAny, samples, raysExtend, raysShadow;
   unsigned long long inner[2], prims[2], planes[2];  // [0] path extension, [1] light visibility
   float innerWaveIters[2], primWaveIters[2];
 };
@@ -56,6 +63,7 @@ struct PathBuf {
   Counts *counts;
   int32_t P, npix;
 };
+static_assert(offsetof(Counts, nNext) == offsetof(Counts, nHit) + 4 && offsetof(Counts, nHit) % 8 == 0, "nHit/nNext form one 64-bit word");
 
 // Appends the lanes with `pred` to a queue with one atomic per wavefront; lane order is kept inside the wavefront.
 // Must be reached by every lane of the wavefront.
@@ -68,6 +76,28 @@ RT_DEV uint32_t queueSlot(uint32_t *counter, bool pred) {
   if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
   base = __shfl(base, leader);
   return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// Appends to two queues at once with ONE atomic per block: `counters` is {countA, countB} as a 64-bit word. Lane order is
+// kept inside the block. Must be reached by every thread of the block.
+RT_DEV void queueSlots2(uint32_t *counters, bool predA, bool predB, uint32_t &slotA, uint32_t &slotB) {
+  __shared__ uint32_t waveA[kBlock / 64], waveB[kBlock / 64];
+  __shared__ unsigned long long blockBase;
+  const unsigned long long maskA = __ballot(predA), maskB = __ballot(predB);
+  const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+  if (lane == 0) { waveA[wave] = (uint32_t)__popcll(maskA); waveB[wave] = (uint32_t)__popcll(maskB); }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long add = 0;
+    for (int w = 0; w < kBlock / 64; ++w) add += (unsigned long long)waveA[w] | ((unsigned long long)waveB[w] << 32);
+    blockBase = add ? atomicAdd(reinterpret_cast<unsigned long long *>(counters), add) : 0ull;
+  }
+  __syncthreads();
+  uint32_t a = (uint32_t)blockBase, b = (uint32_t)(blockBase >> 32);
+  for (uint32_t w = 0; w < wave; ++w) { a += waveA[w]; b += waveB[w]; }
+  const unsigned long long below = (1ull << lane) - 1ull;
+  slotA = a + (uint32_t)__popcll(maskA & below);
+  slotB = b + (uint32_t)__popcll(maskB & below);
 }
 
 template <bool COUNT>
@@ -132,8 +162,12 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DevScene S, PathBuf B, const 
       B.rayD[i] = make_float4(d.x, d.y, d.z, 0);
     }
   }
-  uint32_t q = queueSlot(&B.counts->nActive, alive);
-  if (alive) B.qA[q] = (uint32_t)i;
+  if (S.cameraMode == 1) {  // fisheye drops samples: compact the survivors
+    uint32_t q = queueSlot(&B.counts->nActive, alive);
+    if (alive) B.qA[q] = (uint32_t)i;
+  } else if (valid) {
+    B.qA[i] = (uint32_t)i;  // every sample lives: the queue is the identity and k_begin_pass has set its length
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------- k_extend
@@ -159,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(DevScene S, PathBuf B, const 
   __shared__ uint2 ldsStack[kStackLds * kBlock];
   TravCounters tc = {0, 0, 0, 0.0f, 0.0f};
   ExtendSource src{B, queue};
-  traverseQueue<ExtendSource, false, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[0], ldsStack, tc);
+  traverseQueue<ExtendSource, false, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[0].next, ldsStack, tc);
   flushCounters<COUNT>(B.counts, tc, 0);
 }
 
@@ -171,9 +205,30 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, PathBuf B, const u
   uint32_t slot = 0;
   if (i < B.counts->nActive) {
     slot = queue[i];
+    // Loads that depend only on the path slot, then loads that depend only on the object, each group issued together:
+    // the kernel is bound by the latency of these scattered reads, so they must not wait for one another.
     float4 o4 = B.rayO[slot], d4 = B.rayD[slot];
-    V3 o = v3(o4.x, o4.y, o4.z), d = v3(d4.x, d4.y, d4.z);
     int32_t prim = B.hitPrim[slot];
+    float t = B.hitT[slot];
+    uint32_t rng = B.rng[slot];
+    float4 beta4 = B.beta[slot];
+    V3 o = v3(o4.x, o4.y, o4.z), d = v3(d4.x, d4.y, d4.z);
+    const bool onObject = prim >= 0 && prim < S.numPrims;
+    ObjectData od;
+    od.a = od.b = od.c = od.color = make_float4(0, 0, 0, 0);
+    od.texture = -1; od.material = 0;
+    float nn[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (S.numPrims > 0) {  // uniform; a lane without an object reads object 0 and ignores it
+      const int64_t pc = onObject ? prim : 0;
+      const float4 *P = S.primHit + 3 * pc;
+      od.a = P[0]; od.b = P[1]; od.c = P[2];
+      const float *np = S.primNormals + 9 * pc;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) nn[k] = np[k];
+      od.material = S.primMaterial[pc];
+      od.color = S.primColor[pc];
+      od.texture = S.primTexture[pc];
+    }
     if (prim < 0) {
       // miss: add every light's emittedLight(direction) (raytracer.cpp:217-223); only environment lights emit
       RGBA L = rgba(B.L[slot]);
@@ -181,7 +236,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, PathBuf B, const u
       B.L[slot] = f4(L);
     } else {
       isHit = true;
-      float t = B.hitT[slot];
       V3 nd = normalized(d);
       V3 point = t * nd + o;  // IntersectionInfo::point as the primitive computed it
       V3 normal;
@@ -193,8 +247,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, PathBuf B, const u
         matIdx = pl.material;
         objColor = rgba(pl.color[0], pl.color[1], pl.color[2], pl.color[3]);
       } else {
-        const float4 *P = S.primHit + 3 * (int64_t)prim;
-        float4 a = P[0], b = P[1], c = P[2];
+        float4 a = od.a, b = od.b, c = od.c;
         bool sphere = (__float_as_uint(a.w) | __float_as_uint(b.x) | __float_as_uint(b.y)) == 0u;
         if (sphere) {
           normal = normalized(point - v3(a.x, a.y, a.z));  // Object.cpp:98
@@ -205,21 +258,19 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, PathBuf B, const u
           float b2 = dot(e1, q);
           float b3 = dot(e2, q);
           float b1 = 1.0f - b3 - b2;
-          const float *nn = S.primNormals + 9 * (int64_t)prim;
           normal = normalized(v3(nn) * b1 + v3(nn + 3) * b2 + v3(nn + 6) * b3);
         }
-        matIdx = S.primMaterial[prim];
-        objColor = rgba(S.primColor[prim]);
+        matIdx = od.material;
+        objColor = rgba(od.color);
       }
       V3 wo = -nd;
       V3 outNormal = faceForward(wo, normal);
       V3 biased = point + S.bias * outNormal;  // raytracer.cpp:228
-      uint32_t rng = B.rng[slot];
-      RGBA beta = rgba(B.beta[slot]);
+      RGBA beta = rgba(beta4);
       // Inputs of the direct-light term L += beta * (getColor(biased) * sum_lights intensity), finished by k_shadow once
       // visibility is known. Each light's unshadowed intensity (src/scene/Object.cpp:12-16, 27-34, 41-46) is evaluated
       // here, in light order, so that environment lights draw their hemisphere direction before the BSDF draws.
-      RGBA color = getColor(S, prim, biased);
+      RGBA color = getColor(S, prim, biased, od);
       B.shPoint[slot] = make_float4(biased.x, biased.y, biased.z, 0);
       B.shColor[slot] = f4(color);
       B.shWeight[slot] = f4(beta);
@@ -261,9 +312,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, PathBuf B, const u
       B.rng[slot] = rng;
     }
   }
-  uint32_t qh = queueSlot(&B.counts->nHit, isHit);
+  uint32_t qh, qn;
+  queueSlots2(&B.counts->nHit, isHit, continues, qh, qn);
   if (isHit) B.qHit[qh] = slot;
-  uint32_t qn = queueSlot(&B.counts->nNext, continues);
   if (continues) queueNext[qn] = slot;
 }
 
@@ -307,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow(DevScene S, PathBuf B) {
   __shared__ uint2 ldsStack[kStackLds * kBlock];
   TravCounters tc = {0, 0, 0, 0.0f, 0.0f};
   ShadowSource src{S, B, B.counts->nHit};
-  traverseQueue<ShadowSource, true, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[1], ldsStack, tc);
+  traverseQueue<ShadowSource, true, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[1].next, ldsStack, tc);
   flushCounters<COUNT>(B.counts, tc, 1);
 }
 
@@ -333,14 +384,14 @@ __global__ void k_advance(PathBuf B, int32_t numPointLights, int32_t numAnyLight
   c->nActive = c->nNext;
   c->nNext = 0;
   c->nHit = 0;
-  c->ticket[0] = 0; c->ticket[1] = 0;
+  c->ticket[0].next = 0; c->ticket[1].next = 0;
 }
-__global__ void k_begin_pass(PathBuf B) {
+__global__ void k_begin_pass(PathBuf B, uint32_t nActive) {
   Counts *c = B.counts;
-  c->nActive = 0; c->nNext = 0; c->nHit = 0;
-  c->ticket[0] = 0; c->ticket[1] = 0;
+  c->nActive = nActive; c->nNext = 0; c->nHit = 0;
+  c->ticket[0].next = 0; c->ticket[1].next = 0;
 }
-__global__ void k_reset_trace_ticket(Counts *c) { c->ticket[2] = 0; }
+__global__ void k_reset_trace_ticket(Counts *c) { c->ticket[2].next = 0; }
 __global__ void k_count_samples(PathBuf B, unsigned long long n) { B.counts->samples += n; }  // rejected fisheye samples count too
 
 // Per pixel: fold this pass's samples, in sample order, into the running sum (raytracer.cpp:48-51).
@@ -441,7 +492,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_primary(DevScene S, int32_t x0
   __shared__ uint2 ldsStack[kStackLds * kBlock];
   TravCounters tc = {0, 0, 0, 0.0f, 0.0f};
   PrimarySource src{S, x0, y0, w, h, outPrim, outT};
-  traverseQueue<PrimarySource, false, false, kStackLds, kBlock>(S, src, &counts->ticket[2], ldsStack, tc);
+  traverseQueue<PrimarySource, false, false, kStackLds, kBlock>(S, src, &counts->ticket[2].next, ldsStack, tc);
   flushCounters<false>(counts, tc, 0);
 }
 
@@ -495,7 +546,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene S, int64_t n, co
   __shared__ uint2 ldsStack[kStackLds * kBlock];
   TravCounters tc = {0, 0, 0, 0.0f, 0.0f};
   RaysSource<ANY> src{S, n, origins, directions, outPrim, outT, outPoint, outNormal, outOccluded};
-  traverseQueue<RaysSource<ANY>, ANY, false, kStackLds, kBlock>(S, src, &counts->ticket[2], ldsStack, tc);
+  traverseQueue<RaysSource<ANY>, ANY, false, kStackLds, kBlock>(S, src, &counts->ticket[2].next, ldsStack, tc);
   flushCounters<false>(counts, tc, 0);
 }
 
@@ -1079,7 +1130,7 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
     int sppThis = std::min(sppPass, S.numRays - sBase);
     int64_t n = npix * sppThis;
     unsigned grid = gridFor(n);
-    k_begin_pass<<<1, 1, 0, st>>>(B);
+    k_begin_pass<<<1, 1, 0, st>>>(B, S.cameraMode == 1 ? 0u : (uint32_t)n);
     if ((rc = beginEvent(s, CAT_RAYGEN, timing))) return rc;
     k_raygen<<<grid, kBlock, 0, st>>>(S, B, s->pixList, sBase, sppThis, params->seed);
     k_count_samples<<<1, 1, 0, st>>>(B, (unsigned long long)n);
