@@ -91,7 +91,13 @@ RT_DEV float intersectAABBFinite(V3 o, V3 inv, float mnx, float mny, float mnz, 
   return (tmax >= tmin && tmax > 0) ? tmin : kInf;
 }
 
-constexpr uint32_t kTicketChunkMax = 256, kTicketChunkMin = 64;  // a refill takes up to 64 indices: a chunk must cover one
+#ifndef RT_CHUNK_MAX
+#define RT_CHUNK_MAX 256
+#endif
+#ifndef RT_CHUNK_DIV
+#define RT_CHUNK_DIV 16
+#endif
+constexpr uint32_t kTicketChunkMax = RT_CHUNK_MAX, kTicketChunkMin = 64, kChunksPerWave = RT_CHUNK_DIV;  // a refill takes up to 64 indices: a chunk must cover one
 
 enum { TRAV_CLOSEST = 0, TRAV_ANY = 1, TRAV_POINT_LIGHT = 2 };
 
@@ -112,18 +118,18 @@ constexpr int64_t kMaxInnerNodes = (int64_t)1 << 26;      // * 64 B  < 4 GiB
 constexpr int64_t kMaxObjects = ((int64_t)1 << 32) / 48;  // * 48 B  < 4 GiB
 constexpr int kMaxTreeDepth = kMaxStack;
 
-// Traversal engine. Every wavefront pulls queries from a queue (one atomic per refill) and traces one query per lane.
-// Each lane always has exactly one pending operation:
+// Traversal engine. Every wavefront pulls queries from a queue (one atomic per chunk of 64-256 indices) and traces one
+// query per lane. Each lane always has exactly one pending operation:
 //     INNER   test the two child boxes of an inner node, descend / push / pop
 //     PRIM    test one object of the current leaf
 //     FINISH  planes + result write-out of a query whose BVH part is over
 //     IDLE    no query
-// and each loop iteration the whole wavefront executes ONE kind of operation, chosen by lane count: results are
-// written once kFinishMin lanes wait for it, the queue is visited once kRefillMin lanes are idle, otherwise the more
-// popular of INNER / PRIM runs and the minority waits until it has become the majority. Incoherent rays therefore do
-// not serialise the wavefront through both loop bodies every iteration, and a few long traversals do not leave most
-// lanes waiting: finished queries are REPLACED by new ones. Per query, nodes and objects are still visited in exactly
-// the reference's order. The grid is sized to fill the GPU once (persistent wavefronts); a wavefront ends when the
+// The wavefront votes: results are written once kFinishMin lanes wait for it, the queue is visited once kRefillMin
+// lanes are idle, otherwise the more popular of INNER / PRIM runs in a tight loop of its own for as long as its lanes
+// are still the majority of the working lanes, while the minority waits until it has become the majority. Incoherent
+// rays therefore do not serialise the wavefront through both loop bodies every iteration, and a few long traversals
+// do not leave most lanes waiting: finished queries are REPLACED by new ones. Per query, nodes and objects are still
+// visited in exactly the reference's order. The grid is sized to fill the GPU once (persistent wavefronts); a wavefront ends when the
 // queue is exhausted and its own lanes are done, so nothing ever waits on another wavefront.
 //
 // Query kinds:
@@ -147,9 +153,6 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
   const uint32_t laneId = __lane_id();
   const char *nodeBase = reinterpret_cast<const char *>(S.nodes);
   const char *primBase = reinterpret_cast<const char *>(S.primHit);
-  // Per-lane stack: entries [lo, sp) live in LDS (slot = index % K; entry slot s of lane l is ldsStack[s * BLOCK + l],
-  // so lanes never share a bank), entries [0, lo) have been spilled to per-lane scratch. sp/lo are registers; only
-  // the spill array is addressed dynamically.
   uint2 *stackCol = ldsStack + threadIdx.x;
   uint2 spill[kMaxStack - K];
   enum { OP_IDLE = 0, OP_INNER = 1, OP_PRIM = 2, OP_FINISH = 3, OP_FINISH_EARLY = 4 };
@@ -161,24 +164,50 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
   int sp = 0, lo = 0, mode = TRAV_CLOSEST;
   bool finite = true;
   bool exhausted = false;  // wave-uniform: the queue has no more queries
-  uint32_t chunkPos = 0, chunkEnd = 0;
-  // chunk size: about 16 chunks per wavefront of the grid, so the last chunks do not leave most of the GPU idle
-  const uint32_t kTicketChunk = min(kTicketChunkMax, max(kTicketChunkMin, total / (gridDim.x * (BLOCK / 64) * 16u)));
   bool waveExact = false;  // wave-uniform: some lane holds a ray the min/max slab test is not valid for
+  uint32_t chunkPos = 0, chunkEnd = 0;
+  const uint32_t kTicketChunk = min(kTicketChunkMax, max(kTicketChunkMin, total / (gridDim.x * (BLOCK / 64) * kChunksPerWave)));
+
+  // an inner node becomes an INNER operation, a leaf a run of PRIM operations
+  auto enter = [&](int32_t next) {
+    if (next >= 0) {
+      cur = next; op = OP_INNER;
+    } else {
+      int32_t count = (next >> 24) & 0x7f;
+      pi = next & 0xffffff;
+      if (count == 0) {
+        BigLeaf bl = S.bigLeaves[next & 0x7fffffff];
+        pi = bl.start; count = bl.count;
+      }
+      pe = pi + count;
+      op = OP_PRIM;
+    }
+  };
+  // next stack entry whose box entry distance is still below the closest hit (src/acceleration/BVH.cpp:302-305);
+  // none left: the BVH part of the query is over
+  auto popNext = [&]() {
+    op = OP_FINISH;
+    while (sp > 0) {
+      --sp;
+      // A spilled entry is first copied back into its LDS slot (rare), so that the read below is always a plain LDS
+      // read of one address; reading "LDS or spill" directly makes the compiler select between the two addresses
+      // and issue a generic (flat) load.
+      uint2 *slot = stackCol + (sp & (K - 1)) * BLOCK;
+      if (sp < lo) { lo = sp; *slot = spill[sp]; }
+      uint2 e = *slot;
+      if (__uint_as_float(e.x) < tBest) { enter((int32_t)e.y); break; }
+    }
+  };
 
   while (true) {
-    bool needPop = false, haveNext = false;
-    int32_t next = 0;
     const unsigned long long mInner = __ballot(op == OP_INNER), mPrim = __ballot(op == OP_PRIM);
     const int nInner = __popcll(mInner), nPrim = __popcll(mPrim);
     const int nOther = 64 - nInner - nPrim;  // finished + idle lanes
-    bool special = false;
     if (nOther >= kFinishMin || nInner + nPrim == 0) {
       const unsigned long long mFinish = __ballot(op >= OP_FINISH);
       const int nFinish = __popcll(mFinish), nIdle = nOther - nFinish;
       if (nFinish > 0 && (nFinish >= kFinishMin || nInner + nPrim == 0)) {
         // -------------------------------------------------------------- FINISH: planes, result, lane becomes idle
-        special = true;
         if (op >= OP_FINISH) {
           bool occluded = op == OP_FINISH_EARLY;
           if (op == OP_FINISH) {
@@ -212,9 +241,10 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
           finite = true;
         }
         waveExact = __ballot(!finite) != 0ull;
-      } else if (!exhausted && nIdle >= kRefillMin) {
+        continue;
+      }
+      if (!exhausted && nIdle >= kRefillMin) {
         // -------------------------------------------------------------- REFILL idle lanes from the queue
-        special = true;
         const unsigned long long mIdle = __ballot(op == OP_IDLE);
         int leader = __ffsll((long long)mIdle) - 1;
         // Queue indices come from a wave-local chunk [chunkPos, chunkEnd); one atomic on the shared counter buys
@@ -244,19 +274,21 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
             finite = S.boxesFinite && isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z) && inv.x != 0 && inv.y != 0 &&
                      inv.z != 0 && isfinite(o.x) && isfinite(o.y) && isfinite(o.z);
             float rootDist = intersectAABB(o, inv, S.rootMin[0], S.rootMin[1], S.rootMin[2], S.rootMax[0], S.rootMax[1], S.rootMax[2]);
-            if (rootDist < kInf) { next = S.rootRef; haveNext = true; }
+            if (rootDist < kInf) enter(S.rootRef);
           }
         }
         waveExact = __ballot(!finite) != 0ull;
-      } else if (nInner + nPrim == 0) {
-        break;  // every lane idle and the queue exhausted
+        continue;
       }
+      if (nInner + nPrim == 0) break;  // every lane idle and the queue exhausted
     }
-    if (!special) {
-      if (nInner >= nPrim) {
-        // -------------------------------------------------------------- INNER: both child boxes of the current node
+    const int stay = (nInner + nPrim) >> 1;  // leave a phase once its lanes are a minority of the working lanes
+    if (nInner >= nPrim) {
+      // ---------------------------------------------------------------- INNER: both child boxes of the current node
+      int n = nInner;
+      do {
         if (op == OP_INNER) {
-          if (COUNT) { ++tc.inner; tc.innerWaveIters += 1.0f / (float)nInner; }
+          if (COUNT) { ++tc.inner; tc.innerWaveIters += 1.0f / (float)n; }
           const float4 *N = reinterpret_cast<const float4 *>(nodeBase + ((uint32_t)cur << 6));
           float4 a = N[0], b = N[1], c = N[2];
           int4 r = reinterpret_cast<const int4 *>(N)[3];
@@ -278,14 +310,17 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
             stackCol[(sp & (K - 1)) * BLOCK] = make_uint2(__float_as_uint(swap ? dl : dr), (uint32_t)(swap ? r.x : r.y));
             ++sp;
           }
-          next = (hl && !swap) ? r.x : r.y;
-          haveNext = hl || hr;
-          needPop = !haveNext;
+          if (hl || hr) enter((hl && !swap) ? r.x : r.y);
+          else popNext();
         }
-      } else {
-        // -------------------------------------------------------------- PRIM: one object of the current leaf
+        n = __popcll(__ballot(op == OP_INNER));
+      } while (n > stay);
+    } else {
+      // ---------------------------------------------------------------- PRIM: one object of the current leaf
+      int n = nPrim;
+      do {
         if (op == OP_PRIM) {
-          if (COUNT) { ++tc.prims; tc.primWaveIters += 1.0f / (float)nPrim; }
+          if (COUNT) { ++tc.prims; tc.primWaveIters += 1.0f / (float)n; }
           const float4 *P = reinterpret_cast<const float4 *>(primBase + (uint32_t)pi * 48u);
           bool accepted = intersectPrim(S, P[0], P[1], P[2], pi, o, nd, tBest, primBest);
           ++pi;
@@ -298,39 +333,10 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
               if (magnitude(o - hp) < bulbDist) op = OP_FINISH_EARLY;
             }
           }
-          needPop = op == OP_PRIM && pi == pe;
+          if (op == OP_PRIM && pi == pe) popNext();
         }
-      }
-    }
-    // ------------------------------------------------------------------ common tail: next node of lanes that need one
-    if (needPop) {
-      // next stack entry whose box entry distance is still below the closest hit (src/acceleration/BVH.cpp:302-305)
-      op = OP_FINISH;
-      while (sp > 0) {
-        --sp;
-        // A spilled entry is first copied back into its LDS slot (rare), so that the read below is always a plain LDS
-        // read of one address; reading "LDS or spill" directly makes the compiler select between the two addresses
-        // and issue a generic (flat) load.
-        uint2 *slot = stackCol + (sp & (K - 1)) * BLOCK;
-        if (sp < lo) { lo = sp; *slot = spill[sp]; }
-        uint2 e = *slot;
-        if (__uint_as_float(e.x) < tBest) { next = (int32_t)e.y; haveNext = true; break; }
-      }
-    }
-    if (haveNext) {
-      // an inner node becomes an INNER operation, a leaf a run of PRIM operations
-      if (next >= 0) {
-        cur = next; op = OP_INNER;
-      } else {
-        int32_t count = (next >> 24) & 0x7f;
-        pi = next & 0xffffff;
-        if (count == 0) {
-          BigLeaf bl = S.bigLeaves[next & 0x7fffffff];
-          pi = bl.start; count = bl.count;
-        }
-        pe = pi + count;
-        op = OP_PRIM;
-      }
+        n = __popcll(__ballot(op == OP_PRIM));
+      } while (n > stay);
     }
   }
 }
