@@ -103,10 +103,16 @@ enum { TRAV_CLOSEST = 0, TRAV_ANY = 1, TRAV_POINT_LIGHT = 2 };
 
 // Scheduling thresholds of the traversal engine (lanes of one 64-lane wavefront).
 #ifndef RT_REFILL_MIN
-#define RT_REFILL_MIN 12
+#define RT_REFILL_MIN 16
 #endif
 #ifndef RT_FINISH_MIN
-#define RT_FINISH_MIN 12
+#define RT_FINISH_MIN 16
+#endif
+#ifndef RT_STAY_INNER
+#define RT_STAY_INNER 3
+#endif
+#ifndef RT_STAY_PRIM
+#define RT_STAY_PRIM 1
 #endif
 constexpr int kRefillMin = RT_REFILL_MIN;  // idle lanes before the wavefront goes back to the queue
 constexpr int kFinishMin = RT_FINISH_MIN;   // finished queries waiting before their results are written out
@@ -125,8 +131,8 @@ constexpr int kMaxTreeDepth = kMaxStack;
 //     FINISH  planes + result write-out of a query whose BVH part is over
 //     IDLE    no query
 // The wavefront votes: results are written once kFinishMin lanes wait for it, the queue is visited once kRefillMin
-// lanes are idle, otherwise the more popular of INNER / PRIM runs in a tight loop of its own for as long as its lanes
-// are still the majority of the working lanes, while the minority waits until it has become the majority. Incoherent
+// lanes are idle, otherwise the more popular of INNER / PRIM runs in a tight loop of its own until too few of its lanes
+// are left, while the minority waits until it has become the majority. Incoherent
 // rays therefore do not serialise the wavefront through both loop bodies every iteration, and a few long traversals
 // do not leave most lanes waiting: finished queries are REPLACED by new ones. Per query, nodes and objects are still
 // visited in exactly the reference's order. The grid is sized to fill the GPU once (persistent wavefronts); a wavefront ends when the
@@ -282,7 +288,9 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
       }
       if (nInner + nPrim == 0) break;  // every lane idle and the queue exhausted
     }
-    const int stay = (nInner + nPrim) >> 1;  // leave a phase once its lanes are a minority of the working lanes
+    // a phase ends once its lanes have fallen to 3/8 (INNER) or 1/8 (PRIM) of the lanes that had work at the vote:
+    // measured best on MI355X (a PRIM phase is short, so running it almost dry costs little and saves votes)
+    const int stayInner = ((nInner + nPrim) * RT_STAY_INNER) >> 3, stayPrim = ((nInner + nPrim) * RT_STAY_PRIM) >> 3;
     if (nInner >= nPrim) {
       // ---------------------------------------------------------------- INNER: both child boxes of the current node
       int n = nInner;
@@ -314,7 +322,7 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
           else popNext();
         }
         n = __popcll(__ballot(op == OP_INNER));
-      } while (n > stay);
+      } while (n > stayInner);
     } else {
       // ---------------------------------------------------------------- PRIM: one object of the current leaf
       int n = nPrim;
@@ -336,7 +344,7 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
           if (op == OP_PRIM && pi == pe) popNext();
         }
         n = __popcll(__ballot(op == OP_PRIM));
-      } while (n > stay);
+      } while (n > stayPrim);
     }
   }
 }
