@@ -99,7 +99,7 @@ RT_DEV float intersectAABBFinite(V3 o, V3 inv, float mnx, float mny, float mnz, 
 #endif
 constexpr uint32_t kTicketChunkMax = RT_CHUNK_MAX, kTicketChunkMin = 64, kChunksPerWave = RT_CHUNK_DIV;  // a refill takes up to 64 indices: a chunk must cover one
 
-enum { TRAV_CLOSEST = 0, TRAV_ANY = 1, TRAV_POINT_LIGHT = 2 };
+enum { TRAV_CLOSEST = 0, TRAV_ANY = 1, TRAV_POINT_LIGHT = 2, TRAV_SKIP = 3 };
 
 // Scheduling thresholds of the traversal engine (lanes of one 64-lane wavefront).
 #ifndef RT_REFILL_MIN
@@ -146,6 +146,7 @@ constexpr int kMaxTreeDepth = kMaxStack;
 //                     first accepted hit that already satisfies its predicate |origin - hit| < bulbDist. Every float
 //                     operation between t and that length is monotone in t, and later accepted hits only have smaller
 //                     t, so the final closest hit would satisfy the predicate too: same answer, less work.
+//   TRAV_SKIP         (returned by Source::fetch) the answer of this query cannot matter: nothing is traced or stored
 // RUNTIME_MODE = false compiles the TRAV_CLOSEST loop only.
 //
 // Source (by reference):
@@ -274,8 +275,9 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
           item = src.fetch(idx, o, d, mode, bulbDist);
           nd = normalized(d);
           tBest = kInf; primBest = -1; sp = 0; lo = 0;
-          op = OP_FINISH;
-          if (S.rootRef != kNoBvh) {
+          const bool skip = RUNTIME_MODE && mode == TRAV_SKIP;
+          op = skip ? OP_IDLE : OP_FINISH;
+          if (S.rootRef != kNoBvh && !skip) {
             inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // src/acceleration/BVH.cpp:293
             finite = S.boxesFinite && isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z) && inv.x != 0 && inv.y != 0 &&
                      inv.z != 0 && isfinite(o.x) && isfinite(o.y) && isfinite(o.z);

@@ -46,6 +46,8 @@ struct Counts {
   alignas(128) uint32_t nHit;     // appended by k_shade; {nHit, nNext} are added to as ONE 64-bit word
   uint32_t nNext;
   Ticket ticket[3];               // [0] path extension, [1] light visibility, [2] trace-only kernels
+  alignas(128) unsigned long long skipPoint;  // visibility queries not traced (see ShadowSource), by query kind
+  unsigned long long skipAny;
   alignas(128) unsigned long long raysClosest, raysAny, samples, raysExtend, raysShadow;
   unsigned long long inner[2], prims[2], planes[2];  // [0] path extension, [1] light visibility
   float innerWaveIters[2], primWaveIters[2];
@@ -321,18 +323,29 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, PathBuf B, const u
 // ---------------------------------------------------------------------------------------------------- k_shadow
 // One visibility query per (hit path, light), light-major so that a wavefront traces rays toward the same light.
 // A light that turns out to be hidden has its stored contribution replaced by RGBAColor(0, 0, 0, 1).
+// A light whose unshadowed contribution is already (0, 0, 0) — a surface facing away from a point or distant light —
+// adds the same nothing whether it is visible or not (the alpha of the sum is 1 from the start, src/scene/raytracer.cpp
+// :199), so its query is not traced. The reference traces it; such queries are counted apart.
 struct ShadowSource {
   const DevScene &S;
   const PathBuf &B;
   uint32_t nHit;
+  uint32_t skippedPoint = 0, skippedAny = 0;
   RT_DEV uint32_t total() const { return nHit * (uint32_t)S.numLights; }
-  RT_DEV uint32_t fetch(uint32_t idx, V3 &o, V3 &d, int &mode, float &bulbDist) const {
+  RT_DEV uint32_t fetch(uint32_t idx, V3 &o, V3 &d, int &mode, float &bulbDist) {
     uint32_t k = idx / nHit;
     uint32_t slot = B.qHit[idx - k * nHit];
     const DevLight &l = S.lights[k];
     float4 p4 = B.shPoint[slot];
+    float4 c4 = B.lightC[(int64_t)k * B.P + slot];
     o = v3(p4.x, p4.y, p4.z);
     mode = TRAV_ANY; bulbDist = 0.0f;
+    if (c4.x == 0.0f && c4.y == 0.0f && c4.z == 0.0f) {
+      if (l.type == RT_LIGHT_POINT) ++skippedPoint; else ++skippedAny;
+      d = v3(0, 0, 1);
+      mode = TRAV_SKIP;
+      return idx;
+    }
     if (l.type == RT_LIGHT_DISTANT) {
       d = v3(l.v);  // Object.cpp:7-10
     } else if (l.type == RT_LIGHT_POINT) {
@@ -360,6 +373,12 @@ __global__ __launch_bounds__(kBlock) void k_shadow(DevScene S, PathBuf B) {
   ShadowSource src{S, B, B.counts->nHit};
   traverseQueue<ShadowSource, true, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[1].next, ldsStack, tc);
   flushCounters<COUNT>(B.counts, tc, 1);
+  uint32_t sp = src.skippedPoint, sa = src.skippedAny;
+  for (int off = 32; off > 0; off >>= 1) { sp += __shfl_down(sp, off); sa += __shfl_down(sa, off); }
+  if (__lane_id() == 0) {  // one wavefront = up to two atomics per launch, on a line of their own
+    if (sp) atomicAdd(&B.counts->skipPoint, (unsigned long long)sp);
+    if (sa) atomicAdd(&B.counts->skipAny, (unsigned long long)sa);
+  }
 }
 
 // L += beta * (getColor(point) * sum over lights, in scene order) — src/scene/raytracer.cpp:198-206, 231
@@ -1178,12 +1197,13 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
   if (stats) {
     std::memset(stats, 0, sizeof *stats);
     stats->cameraSamples = hc.samples;
-    stats->raysClosest = hc.raysClosest;
-    stats->raysAny = hc.raysAny;
+    stats->raysClosest = hc.raysClosest - hc.skipPoint;
+    stats->raysAny = hc.raysAny - hc.skipAny;
+    stats->raysSkipped = hc.skipPoint + hc.skipAny;
     stats->innerExpansions = hc.inner[0] + hc.inner[1];
     stats->primTests = hc.prims[0] + hc.prims[1];
     stats->planeTests = hc.planes[0] + hc.planes[1];
-    stats->raysExtend = hc.raysExtend; stats->raysShadow = hc.raysShadow;
+    stats->raysExtend = hc.raysExtend; stats->raysShadow = hc.raysShadow - hc.skipPoint - hc.skipAny;
     stats->innerExtend = hc.inner[0]; stats->primExtend = hc.prims[0];
     stats->innerShadow = hc.inner[1]; stats->primShadow = hc.prims[1];
     stats->laneUseInnerExtend = hc.innerWaveIters[0] > 0 ? hc.inner[0] / (64.0 * hc.innerWaveIters[0]) : 0.0;
