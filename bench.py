@@ -147,9 +147,20 @@ def main():
     else:
         kname, kb, kms, krays, klaunch = "k_shadow", b_sh, ms_sh, rays_sh, launches_sh
     achieved = (krays * kb) / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    # HBM bytes per launch from the PMC passes of this same workload (tools/profile_on_box.sh -> tools/pmc_traffic.py);
+    # counters cannot be read from inside this process, so the figure is the committed one, and only for the default run.
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    default_workload = (args.spp, args.size, args.grid, args.spp_pass, args.tile, world) == (256, 1080, 512, 0, 32, 1)
+    if default_workload and os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath))["kernels"][kname]["hbm_bytes_per_launch"]
+        except (KeyError, ValueError):
+            traffic = None
     roofline = {
         "bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/pmc_traffic.json)",
+        "algorithmic_bytes_per_launch": int(krays * kb / max(1, klaunch)),
         "bytes_per_ray": round(kb, 1), "rays_per_launch": round(krays / max(1, klaunch), 1),
         "avg_launch_ms": round(kms / max(1, klaunch), 4),
         "lane_use": {"extend_inner": round(cst.laneUseInnerExtend, 3), "extend_prim": round(cst.laneUsePrimExtend, 3),

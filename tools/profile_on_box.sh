@@ -3,12 +3,12 @@
 # Every pass is its own rocprofv3 run with its own time limit; outputs land under gpurun_out/prof_<tag>/.
 set -u
 TAG=${1:-r1}
-SPP=${2:-32}
+ARGS=${2:---steps 2 --warmup 1}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --spp $SPP --steps 1 --warmup 1 --cpu-seconds 0"
+BENCH="python3 $ROOT/bench.py $ARGS --cpu-seconds 0"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.log" 2>&1 || { echo "trace pass failed"; tail -5 "$OUT/trace.log"; exit 1; }
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o fetch -- $BENCH > "$OUT/pmc_fetch.log" 2>&1 || { echo "fetch pass failed"; tail -5 "$OUT/pmc_fetch.log"; exit 1; }
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" -o write -- $BENCH > "$OUT/pmc_write.log" 2>&1 || { echo "write pass failed"; tail -5 "$OUT/pmc_write.log"; exit 1; }
