@@ -59,6 +59,38 @@ def test_primary_hits_config2_full_size(scenes, golden):
     assert np.array_equal(ids2, ids[410:487, 500:633]) and np.array_equal(t2.view(np.uint32), t[410:487, 500:633].view(np.uint32))
 
 
+def test_full_size_benchmark_scene(scenes, golden):
+    """The scene bench.py renders (1080x1080, ~1.05 M objects, 665 k nodes, textures, five materials, two lights):
+    primary hits against the compiled reference's fixture by hash; incoherent closest/any queries bit-exact against
+    the oracle; a 2-spp frame within the PSNR bar; tile partitions recombine to the whole frame bit for bit."""
+    g = golden("readme")
+    hs, dev, orc = scenes("readme")
+    ids, t = dev.trace_primary()
+    assert int((ids >= 0).sum()) == int(g["num_hits"])
+    assert sha1(ids) == str(g["hit_ids_sha1"]) and sha1(t.view(np.uint32)) == str(g["hit_tbits_sha1"])
+    o, d = _random_rays(200_000, 11)
+    gi, gt, gp, gn = dev.trace_closest(o, d)
+    oi, ot, op_, on = orc.trace_closest(o, d)
+    assert np.array_equal(gi, oi) and np.array_equal(gt.view(np.uint32), ot.view(np.uint32))
+    assert np.array_equal(gp.view(np.uint32), op_.view(np.uint32)) and np.array_equal(gn.view(np.uint32), on.view(np.uint32))
+    assert np.array_equal(dev.trace_any(o, d), orc.trace_any(o, d))
+    opt = hs.desc.contents.options
+    two = capi.RtOptions(opt.width, opt.height, opt.bias, opt.exposure, opt.maxBounces, 2, opt.fisheye, opt.focus, opt.lens)
+    full = capi.RtOptions(opt.width, opt.height, opt.bias, opt.exposure, opt.maxBounces, opt.numRays, opt.fisheye, opt.focus, opt.lens)
+    dev.set_view(options=two); orc.set_view(options=two)
+    try:
+        img, st = dev.render(seed=5)
+        ref, ost = orc.render(seed=5)
+        assert st.cameraSamples == ost.cameraSamples == 2 * opt.width * opt.height
+        assert np.array_equal(img[..., 3], ref[..., 3])
+        assert psnr(img[..., :3], ref[..., :3]) >= PSNR_MIN_DB
+        whole = img.copy()
+        parts = sum(dev.render(seed=5, part_index=r, part_count=3, tile=(32, 32))[0] for r in range(3))
+        assert np.array_equal(parts.view(np.uint32), whole.view(np.uint32))
+    finally:
+        dev.set_view(options=full); orc.set_view(options=full)
+
+
 def _random_rays(n, seed, spread=4.0):
     rng = np.random.default_rng(seed)
     o = (rng.normal(size=(n, 3)) * np.array([spread, spread * 0.6, spread]) + np.array([0, 0.3, -3])).astype(np.float32)

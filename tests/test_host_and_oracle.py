@@ -18,7 +18,7 @@ def sha1(a):
     return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-@pytest.mark.parametrize("name", SMALL_SCENES + ["mesh70k"])
+@pytest.mark.parametrize("name", SMALL_SCENES + ["mesh70k", "readme_mid"])
 def test_host_bvh_matches_reference(name, scene_path, golden):
     """Same node array and same object permutation as BVH::BVH (src/acceleration/BVH.cpp:161-182) on the same file."""
     g = golden(name)
@@ -48,6 +48,22 @@ def test_oracle_primary_hits_config2_hash(scene_path, golden):
     assert int((ids >= 0).sum()) == int(g["num_hits"])
     assert sha1(ids) == str(g["hit_ids_sha1"])
     assert sha1(t.view(np.uint32)) == str(g["hit_tbits_sha1"])
+
+
+def test_full_size_benchmark_scene_host_and_oracle(scene_path, golden):
+    """The benchmark scene at full size (~1.05 M objects, 665 k nodes, 1080x1080): the host's parse + BVH build equal
+    the reference's node array and object order, and the oracle's primary hits equal the reference's, by hash."""
+    g = golden("readme")
+    hs = capi.HostScene.load(scene_path("readme")).build()
+    d = hs.desc.contents
+    assert (d.numNodes, d.numPrims) == (int(g["num_nodes"]), int(g["num_prims"]))
+    assert sha1(hs.nodes()) == str(g["bvh_nodes_sha1"])
+    assert sha1(hs.prim_orig_index()) == str(g["bvh_perm_sha1"])
+    osc = oracle_scene(hs.desc)
+    ids, t = osc.trace_primary()
+    assert int((ids >= 0).sum()) == int(g["num_hits"])
+    assert sha1(ids) == str(g["hit_ids_sha1"]) and sha1(t.view(np.uint32)) == str(g["hit_tbits_sha1"])
+    osc.close()
 
 
 @pytest.mark.parametrize("name", SMALL_SCENES)
