@@ -91,6 +91,31 @@ def test_full_size_benchmark_scene(scenes, golden):
         dev.set_view(options=full); orc.set_view(options=full)
 
 
+def test_config5_shape_4k_multi_million_triangles():
+    """BASELINE config 5 in shape (3840x2160, in-memory procedural mesh, GI with point + environment light), at 2 M
+    triangles so that the host build stays short; tools/config5_stress.py runs the 10 M-triangle size."""
+    from tools import config5_stress
+    hs, tris = config5_stress.build_scene(1000, 3840, 2160, 1, 4)
+    hs.build()
+    assert tris > 1_900_000
+    dev, orc = capi.device_scene(hs.desc), oracle_scene(hs.desc)
+    try:
+        gi, gt = dev.trace_primary(0, 1000, 3840, 96)
+        oi, ot = orc.trace_primary(0, 1000, 3840, 96)
+        assert (gi >= 0).sum() > 100_000
+        assert np.array_equal(gi, oi) and np.array_equal(gt.view(np.uint32), ot.view(np.uint32))
+        o, d = _random_rays(100_000, 23)
+        for a, b in zip(dev.trace_closest(o, d), orc.trace_closest(o, d)):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        img, st = dev.render(seed=9)
+        whole = img.copy()
+        parts = sum(dev.render(seed=9, part_index=r, part_count=8, tile=(32, 32))[0] for r in range(8))
+        assert np.array_equal(parts.view(np.uint32), whole.view(np.uint32)), "8-way tile partition must recombine exactly"
+        assert st.cameraSamples == 3840 * 2160
+    finally:
+        dev.close(); orc.close()
+
+
 def _random_rays(n, seed, spread=4.0):
     rng = np.random.default_rng(seed)
     o = (rng.normal(size=(n, 3)) * np.array([spread, spread * 0.6, spread]) + np.array([0, 0.3, -3])).astype(np.float32)
