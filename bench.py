@@ -72,9 +72,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render loop has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # RT_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: ranks share the GPUs there are
+    # and the gather runs over gloo on host tensors. The measured configuration is the default: nccl (= RCCL), one GPU per rank.
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    gpu = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(gpu)
+    tdev = torch.device("cuda", gpu) if backend == "nccl" else torch.device("cpu")
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=tdev)
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
@@ -87,9 +95,9 @@ def main():
     hs = capi.HostScene.load(path).build()
     desc = hs.desc
     d = desc.contents
-    dev = capi.device_scene(desc, device=local_rank)
+    dev = capi.device_scene(desc, device=gpu)
     W, H = d.options.width, d.options.height
-    out = torch.zeros((H, W, 4), dtype=torch.float32, device=torch.device("cuda", local_rank))
+    out = torch.zeros((H, W, 4), dtype=torch.float32, device=tdev)
     setup_s = time.time() - t_setup
 
     gatherer = multi_gpu.TileGather(W, H, (args.tile, args.tile), rank, world, out.device)
@@ -110,8 +118,7 @@ def main():
 
     rays_local = sum(s.raysClosest + s.raysAny for s in stats)
     samples_local = sum(s.cameraSamples for s in stats)
-    agg = torch.tensor([float(elapsed), float(rays_local), float(samples_local)], dtype=torch.float64,
-                       device=torch.device("cuda", local_rank))
+    agg = torch.tensor([float(elapsed), float(rays_local), float(samples_local)], dtype=torch.float64, device=tdev)
     if world > 1:
         tmax = agg[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -198,7 +205,8 @@ def main():
         "config": {"workload": f"README-scene stand-in: {W}x{H}, {o.numRays} spp, {tris} BVH objects + {d.numPlanes} planes, "
                                f"point + environment light, maxBounces {o.maxBounces}",
                    "width": W, "height": H, "spp": o.numRays, "objects": tris, "bvh_nodes": int(d.numNodes),
-                   "parallelism": f"image tiles {args.tile}x{args.tile} interleaved over {world} GPU(s), RCCL gather to rank 0"},
+                   "parallelism": f"image tiles {args.tile}x{args.tile} interleaved over {world} GPU(s), "
+                                  + ("RCCL gather to rank 0" if backend == "nccl" else f"REHEARSAL: {backend} gather, ranks share GPUs")},
         "wall_time_s": round(ms_per_step / 1e3, 3),
         "camera_msamples_per_s": round(samples_total / elapsed / 1e6, 2),
         "rays_per_frame": int(rays_total / args.steps),
