@@ -167,6 +167,7 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
   uint32_t item = 0;
   V3 o = v3(0, 0, 0), nd = o, inv = o;
   float tBest = kInf, bulbDist = 0.0f;
+  float cullD = kInf;  // TRAV_POINT_LIGHT: boxes entered beyond this distance (in units of |d|) cannot matter, see below
   int32_t primBest = -1, cur = 0, pi = 0, pe = 0;
   int sp = 0, lo = 0, mode = TRAV_CLOSEST;
   bool finite = true;
@@ -202,7 +203,7 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
       uint2 *slot = stackCol + (sp & (K - 1)) * BLOCK;
       if (sp < lo) { lo = sp; *slot = spill[sp]; }
       uint2 e = *slot;
-      if (__uint_as_float(e.x) < tBest) { enter((int32_t)e.y); break; }
+      if (__uint_as_float(e.x) < (RUNTIME_MODE ? __builtin_fminf(tBest, cullD) : tBest)) { enter((int32_t)e.y); break; }
     }
   };
 
@@ -277,12 +278,19 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
           tBest = kInf; primBest = -1; sp = 0; lo = 0;
           const bool skip = RUNTIME_MODE && mode == TRAV_SKIP;
           op = skip ? OP_IDLE : OP_FINISH;
+          // A point-light query only asks whether the closest hit lies nearer than the bulb. With |d| = bulbDist >= 1
+          // the reference's culling is conservative (box distances are in units of |d|, t in units of 1, so a box is
+          // never farther than its distance says) and its closest hit is the true one; every object in a box entered
+          // beyond the bulb (distance > 1 in units of |d|, plus a 1 % margin for rounding) is hit beyond the bulb, which
+          // answers the question like no hit at all. Such boxes are skipped. For bulbDist < 1 the reference's culling
+          // can drop nearer hits depending on what it visited before, so nothing is skipped then.
+          cullD = (RUNTIME_MODE && mode == TRAV_POINT_LIGHT && bulbDist >= 1.0f) ? 1.01f : kInf;
           if (S.rootRef != kNoBvh && !skip) {
             inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // src/acceleration/BVH.cpp:293
             finite = S.boxesFinite && isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z) && inv.x != 0 && inv.y != 0 &&
                      inv.z != 0 && isfinite(o.x) && isfinite(o.y) && isfinite(o.z);
             float rootDist = intersectAABB(o, inv, S.rootMin[0], S.rootMin[1], S.rootMin[2], S.rootMax[0], S.rootMax[1], S.rootMax[2]);
-            if (rootDist < kInf) enter(S.rootRef);
+            if (rootDist < cullD) enter(S.rootRef);
           }
         }
         waveExact = __ballot(!finite) != 0ull;
@@ -312,7 +320,8 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
           }
           // Near child first, right only if strictly nearer (src/acceleration/BVH.cpp:322-333); a child that cannot
           // beat the closest hit any more is dropped here instead of at pop time.
-          bool hl = dl < tBest, hr = dr < tBest;
+          const float lim = RUNTIME_MODE ? __builtin_fminf(tBest, cullD) : tBest;
+          bool hl = dl < lim, hr = dr < lim;
           bool both = hl && hr;
           bool swap = both && dr < dl;
           if (both) {
