@@ -44,8 +44,53 @@ def pmc_stats(db):
     return "\n".join(out)
 
 
+def derived(root):
+    """Per kernel: duration, HBM GB/s (FETCH_SIZE doubled: gfx950 counts a 128-byte read request as 64 bytes), VALU
+    utilisation (SQ_ACTIVE_INST_VALU is in 4-cycle units, summed over 1024 SIMDs; GRBM_GUI_ACTIVE summed over 8 XCDs),
+    how a wavefront's resident time splits, cache hit rates."""
+    def load(tag, fn):
+        path = os.path.join(root, tag, fn)
+        if not os.path.exists(path):
+            return {}
+        con = sqlite3.connect(path)
+        out = {}
+        if tag == "trace":
+            cols = [r[1] for r in q(con, "pragma table_info(kernels)")]
+            name = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+            for n, c, avg in q(con, f"select {name}, count(*), avg(end-start) from kernels group by {name}"):
+                out[short(n, 58)] = {"calls": c, "avg_ns": avg}
+        else:
+            cols = [r[1] for r in q(con, "pragma table_info(counters_collection)")]
+            kname = "kernel_name" if "kernel_name" in cols else [c for c in cols if "kernel" in c and "name" in c][0]
+            cname = "counter_name" if "counter_name" in cols else [c for c in cols if "counter" in c and "name" in c][0]
+            for k, c, n, sm in q(con, f"select {kname}, {cname}, count(*), sum(value) from counters_collection group by {kname}, {cname}"):
+                out.setdefault(short(k, 48), {})[c] = sm / n
+        return out
+    tr, fe, wr = load("trace", "trace_results.db"), load("pmc_fetch", "fetch_results.db"), load("pmc_write", "write_results.db")
+    sq, ca = load("pmc_sq", "sq_results.db"), load("pmc_cache", "cache_results.db")
+    rows = [f"{'kernel':<22} {'avg_us':>9} {'HBM_GB/s':>9} {'of_8TB/s':>8} {'VALU_busy':>9} {'wave:wait_mem':>13} {'wait_issue':>10} {'executing':>9} {'L2_hit':>7}"]
+    for k in sorted(tr, key=lambda k: -tr[k]["avg_ns"] * tr[k]["calls"]):
+        us = tr[k]["avg_ns"] / 1e3
+        f, w = fe.get(k, {}).get("FETCH_SIZE"), wr.get(k, {}).get("WRITE_SIZE")
+        gbs = (2 * f + w) * 1024 / (us * 1e-6) / 1e9 if f is not None and w is not None and us > 0 else None
+        s_ = sq.get(k, {})
+        valu = (s_["SQ_ACTIVE_INST_VALU"] * 4 / 1024) / (s_["GRBM_GUI_ACTIVE"] / 8) if "SQ_ACTIVE_INST_VALU" in s_ and s_.get("GRBM_GUI_ACTIVE") else None
+        wc = s_.get("SQ_WAVE_CYCLES")
+        c_ = ca.get(k, {})
+        l2 = c_["TCC_HIT_sum"] / (c_["TCC_HIT_sum"] + c_["TCC_MISS_sum"]) if c_.get("TCC_HIT_sum") is not None and (c_.get("TCC_HIT_sum", 0) + c_.get("TCC_MISS_sum", 0)) > 0 else None
+        fmt = lambda v, p="{:.2f}": "-" if v is None else p.format(v)
+        rows.append(f"{k:<22} {us:>9.1f} {fmt(gbs, '{:.0f}'):>9} {fmt(None if gbs is None else gbs / 8000):>8} {fmt(valu):>9} "
+                    f"{fmt(s_['SQ_WAIT_ANY'] / wc if wc else None):>13} {fmt(s_['SQ_WAIT_INST_ANY'] / wc if wc else None):>10} "
+                    f"{fmt(s_['SQ_ACTIVE_INST_ANY'] / wc if wc else None):>9} {fmt(l2):>7}")
+    return "\n".join(rows)
+
+
 if __name__ == "__main__":
     root = sys.argv[1]
+    if os.path.exists(os.path.join(root, "trace", "trace_results.db")):
+        print("==== derived (per launch averages)")
+        print(derived(root))
+        print()
     for db in sorted(glob.glob(os.path.join(root, "*", "*_results.db"))):
         tag = os.path.basename(os.path.dirname(db))
         print(f"==== {tag} ({os.path.relpath(db, root)})")
