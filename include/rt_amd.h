@@ -134,7 +134,8 @@ typedef struct RtRenderParams {
    * iff i % partCount == partIndex. partCount <= 1 renders the whole image. */
   int32_t partIndex, partCount;
   int32_t tileW, tileH;
-  int32_t samplesPerPass; /* camera samples per pixel traced per wavefront pass; 0 = library default */
+  int32_t samplesPerPass; /* camera samples per pixel traced per wavefront pass; 0 = library default: as many as fit
+                           * in half of the free device memory, at most 64 GiB of path state (184 B per path with 2 lights) */
   int32_t collectCounters;/* non-zero: count traversal work (inner expansions, primitive tests); slower */
   int32_t skipExposure;   /* non-zero: leave out Scene::expose (src/scene/raytracer.cpp:303-312) */
 } RtRenderParams;
