@@ -16,7 +16,7 @@ hs = capi.HostScene.load(d + "/readme.sdml").build()
 dev = capi.device_scene(hs.desc)
 o = hs.desc.contents.options
 for mb in [int(x) for x in os.environ.get('PROBE_BOUNCES', '1,2,4').split(',')]:
-    dev.set_view(options=capi.RtOptions(o.width, o.height, o.bias, o.exposure, mb, 7, o.fisheye, o.focus, o.lens))
+    dev.set_view(options=capi.RtOptions(o.width, o.height, o.bias, o.exposure, mb, int(os.environ.get("PROBE_SPP", "64")), o.fisheye, o.focus, o.lens))
     dev.render(download=False)
     _, st = dev.render(download=False)
     _, c = dev.render(download=False, collect_counters=True)
