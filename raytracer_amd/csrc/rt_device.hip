@@ -609,6 +609,9 @@ struct RtScene {
   int32_t *pixHits = nullptr;
   float4 *fb = nullptr;
   int64_t fbPixels = 0, pixCap = 0;
+  // the pixel list on the device belongs to this partition (a repeated frame does not rebuild and re-upload it)
+  int pixKey[6] = {-1, -1, -1, -1, -1, -1};
+  int64_t pixCount = 0;
   Counts *counts = nullptr;
   std::vector<EventPair> events;
   size_t eventsUsed = 0;
@@ -906,6 +909,7 @@ int ensureRenderBuffers(RtScene *s, int64_t P, int64_t npix, int64_t fbPixels) {
     if (s->pixSum) (void)hipFree(s->pixSum);
     if (s->pixHits) (void)hipFree(s->pixHits);
     s->pixList = nullptr; s->pixSum = nullptr; s->pixHits = nullptr;
+    s->pixKey[0] = -1;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->pixList), npix * sizeof(int32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->pixSum), npix * sizeof(float4)));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->pixHits), npix * sizeof(int32_t)));
@@ -1119,8 +1123,11 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
   const DevScene &S = s->dev;
   int W = S.width, H = S.height;
   if (S.numRays <= 0) return failMsg(RT_ERR_INVALID, "numRays must be positive");
-  std::vector<int32_t> pix = buildPixelList(*params, W, H);
-  int64_t npix = (int64_t)pix.size();
+  const int key[6] = {W, H, params->partIndex, params->partCount, params->tileW, params->tileH};
+  const bool samePartition = s->pixList && std::memcmp(key, s->pixKey, sizeof key) == 0;
+  std::vector<int32_t> pix;
+  if (!samePartition) pix = buildPixelList(*params, W, H);
+  int64_t npix = samePartition ? s->pixCount : (int64_t)pix.size();
   int64_t fbPixels = (int64_t)W * H;
   int sppPass = params->samplesPerPass;
   if (sppPass <= 0) {
@@ -1147,7 +1154,13 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
   HIP_TRY(hipMemsetAsync(s->counts, 0, sizeof(Counts), st));
   HIP_TRY(hipMemsetAsync(s->fb, 0, fbPixels * sizeof(float4), st));
   if (npix > 0) {
-    HIP_TRY(hipMemcpyAsync(s->pixList, pix.data(), npix * 4, hipMemcpyHostToDevice, st));
+    if (!samePartition) {
+      s->pixKey[0] = -1;
+      HIP_TRY(hipMemcpyAsync(s->pixList, pix.data(), npix * 4, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipStreamSynchronize(st));  // `pix` is pageable host memory that goes out of scope
+      std::memcpy(s->pixKey, key, sizeof key);
+      s->pixCount = npix;
+    }
     HIP_TRY(hipMemsetAsync(s->pixSum, 0, npix * sizeof(float4), st));
     HIP_TRY(hipMemsetAsync(s->pixHits, 0, npix * sizeof(int32_t), st));
   }
