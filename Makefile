@@ -12,7 +12,7 @@ HIPFLAGS  := -std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -I$(RO
              -Wall -Wno-unused-parameter
 
 HOST_SRCS := $(HOSTDIR)/rth_scene.cpp $(HOSTDIR)/rth_bvh.cpp $(HOSTDIR)/rth_parse.cpp $(HOSTDIR)/rth_png.cpp $(HOSTDIR)/rth_capi.cpp
-HOST_HDRS := $(HOSTDIR)/rth_scene.h $(HOSTDIR)/rth_math.h $(ROOT)include/rt_amd.h $(ROOT)include/rt_host.h
+HOST_HDRS := $(HOSTDIR)/rth_scene.h $(HOSTDIR)/rth_math.h $(HOSTDIR)/rth_threads.h $(ROOT)include/rt_amd.h $(ROOT)include/rt_host.h
 HIP_SRCS  := $(CSRC)/rt_device.hip
 HIP_HDRS  := $(wildcard $(CSRC)/*.h) $(ROOT)include/rt_amd.h
 
@@ -24,7 +24,7 @@ hip: $(PKG)/libraytracer_amd.so
 cli: $(PKG)/raytracer
 
 $(PKG)/librt_host.so: $(HOST_SRCS) $(HOST_HDRS)
-	$(CXX) $(HOSTFLAGS) -shared $(HOST_SRCS) -o $@ -lz
+	$(CXX) $(HOSTFLAGS) -pthread -shared $(HOST_SRCS) -o $@ -lz
 
 $(PKG)/libraytracer_amd.so: $(HIP_SRCS) $(HIP_HDRS)
 	$(HIPCC) $(HIPFLAGS) -shared $(HIP_SRCS) -o $@

@@ -58,6 +58,12 @@ int rth_png_write_rgba8(const char *path, int32_t width, int32_t height, const u
 void rth_to_srgb8(const float *rgba, int64_t numPixels, uint8_t *rgba8);
 void rth_free(void *p);
 
+/* Host worker threads for parsing, triangle set-up and the BVH build: what `-t N` of the reference's command line
+ * (src/main.cpp:14-25) means here. n <= 0 restores the default (hardware threads, at most 16). The thread count never
+ * changes a result. */
+void rth_set_threads(int32_t n);
+int32_t rth_get_threads(void);
+
 const char *rth_last_error(void);
 
 #ifdef __cplusplus

@@ -138,8 +138,19 @@ def load_host_library():
     L.rth_png_write_rgba8.argtypes = [cp, i32, i32, C.POINTER(C.c_uint8)]
     L.rth_to_srgb8.argtypes = [C.POINTER(f32), C.c_int64, C.POINTER(C.c_uint8)]
     L.rth_free.argtypes = [vp]
+    L.rth_set_threads.argtypes = [i32]; L.rth_set_threads.restype = None
+    L.rth_get_threads.restype = i32
     _host = L
     return L
+
+
+def set_host_threads(n):
+    """Host worker threads for parsing, triangle set-up and the BVH build (`-t N`); n <= 0 = default."""
+    load_host_library().rth_set_threads(int(n))
+
+
+def host_threads():
+    return load_host_library().rth_get_threads()
 
 
 class HostScene:

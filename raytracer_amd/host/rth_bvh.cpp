@@ -1,172 +1,233 @@
-// Binned-SAH BVH builder: decision-for-decision the reference's
-// src/acceleration/BVH.cpp:72-281 (findBestBucketSplit, partition, updateNodeBounds, flatten),
-// because the leaf order it produces decides which primitive wins a tie in t
-// (BVH.cpp:308-313) and therefore the hit ids. Works on an index permutation and
-// reorders scene.prims once at the end.
+// Host BVH build. The TREE is the reference's, decision for decision (src/acceleration/BVH.cpp:72-281: 16 centroid
+// bins per axis, cost = areaL*countL + areaR*countR over 3 x 15 planes, leaf when <= 4 objects / no cheaper split / an
+// empty side, objects regrouped with std::partition), because the leaf order it produces decides which object wins a
+// tie in t (BVH.cpp:308-313) and therefore the hit ids. The SCHEDULE is this library's own: the tree is split top-down
+// with all host threads binning each large node together until the pieces are small, then the pieces are built
+// concurrently, one thread each. Bin boxes and counts are min / max / integer sums, so neither the thread count nor the
+// order of the pieces changes a single bit of the result; node numbers are assigned afterwards by a pre-order walk
+// (left child = index + 1, BVH.cpp:411-428).
 #include <algorithm>
+#include <atomic>
 #include <limits>
 #include <numeric>
 
 #include "rth_scene.h"
+#include "rth_threads.h"
 
 namespace rth {
 namespace {
 
-constexpr int kBuckets = 16;     // N_BUCKETS, BVH.cpp:9
-constexpr int kMinLeafSize = 4;  // MIN_LEAF_SIZE, BVH.cpp:11
+constexpr int kBins = 16;          // N_BUCKETS, BVH.cpp:9
+constexpr int kLeafObjects = 4;    // MIN_LEAF_SIZE, BVH.cpp:11
+constexpr int kSharedNode = 1 << 16;  // nodes with at least this many objects are binned by all threads together
 constexpr float kInf = std::numeric_limits<float>::infinity();
 
-struct Box {  // BVH.h:18-28, BVH.cpp:142-159
-  Vec3 minPoint{kInf, kInf, kInf}, maxPoint{-kInf, -kInf, -kInf};
-  void shrink(const Vec3 &p) {
-    minPoint.x = std::min(minPoint.x, p.x); minPoint.y = std::min(minPoint.y, p.y); minPoint.z = std::min(minPoint.z, p.z);
+struct Bounds {
+  float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
+  void add(const Vec3 &mn, const Vec3 &mx) {
+    lo[0] = std::min(lo[0], mn.x); lo[1] = std::min(lo[1], mn.y); lo[2] = std::min(lo[2], mn.z);
+    hi[0] = std::max(hi[0], mx.x); hi[1] = std::max(hi[1], mx.y); hi[2] = std::max(hi[2], mx.z);
   }
-  void expand(const Vec3 &p) {
-    maxPoint.x = std::max(maxPoint.x, p.x); maxPoint.y = std::max(maxPoint.y, p.y); maxPoint.z = std::max(maxPoint.z, p.z);
+  void add(const Bounds &b) {
+    for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); }
   }
-  float surfaceArea() const {
-    Vec3 e = maxPoint - minPoint;
-    return 2 * (e.x * e.y + e.y * e.z + e.x * e.z);
+  float area() const {  // Box::surfaceArea, BVH.cpp:142-159
+    float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    return 2 * (ex * ey + ey * ez + ex * ez);
   }
 };
 
-struct BuildNode {
-  Vec3 aabbMin, aabbMax;
-  int left = -1, right = -1;  // indices into the build-node pool
-  int start = 0, numObjects = 0;
+struct TreeNode {
+  Bounds box;
+  int left = -1, right = -1;
+  int first = 0, count = 0;  // count > 0: leaf over order[first, first + count)
 };
 
-struct Builder {
-  const std::vector<Prim> &prims;
-  std::vector<int> order;  // order[i] = index into prims of the object at BVH position i
-  std::vector<BuildNode> pool;
+struct Bins {
+  Bounds box[3][kBins];
+  int count[3][kBins] = {};
+  void add(const Bins &o) {
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < kBins; ++b) { box[a][b].add(o.box[a][b]); count[a][b] += o.count[a][b]; }
+  }
+};
 
-  explicit Builder(const std::vector<Prim> &p) : prims(p), order(p.size()) { std::iota(order.begin(), order.end(), 0); }
-  const Prim &at(int i) const { return prims[order[i]]; }
+struct Split { int axis = -1; float position = 0, cost = kInf; };
 
-  void updateNodeBounds(int n) {  // BVH.cpp:184-200
-    BuildNode &node = pool[n];
-    node.aabbMin = Vec3(kInf, kInf, kInf);
-    node.aabbMax = Vec3(-kInf, -kInf, -kInf);
-    int end = node.start + node.numObjects;
-    for (int i = node.start; i < end; ++i) {
-      const Prim &o = at(i);
-      node.aabbMin.x = std::min(node.aabbMin.x, o.aabbMin.x);
-      node.aabbMin.y = std::min(node.aabbMin.y, o.aabbMin.y);
-      node.aabbMin.z = std::min(node.aabbMin.z, o.aabbMin.z);
-      node.aabbMax.x = std::max(node.aabbMax.x, o.aabbMax.x);
-      node.aabbMax.y = std::max(node.aabbMax.y, o.aabbMax.y);
-      node.aabbMax.z = std::max(node.aabbMax.z, o.aabbMax.z);
+class TreeBuilder {
+ public:
+  explicit TreeBuilder(const std::vector<Prim> &p) : prims_(p.size()), order_(p.size()), nodes_(2 * p.size() + 1) {
+    // the build only looks at boxes and centroids: 36 bytes per object instead of the whole record
+    parallelChunks((int64_t)p.size(), 1 << 14, [&](int64_t b, int64_t e) {
+      for (int64_t i = b; i < e; ++i) {
+        const Prim &o = p[(size_t)i];
+        prims_[(size_t)i] = BuildPrim{o.aabbMin, o.aabbMax, o.centroid};
+        order_[(size_t)i] = (int)i;
+      }
+    });
+  }
+  std::vector<int> &order() { return order_; }
+
+  void build() {
+    nodes_[0].first = 0; nodes_[0].count = (int)prims_.size();
+    used_ = 1;
+    nodes_[0].box = boundsOf(0, (int)prims_.size(), true);
+    // top of the tree: one node at a time, every thread on it
+    std::vector<int> open{0}, pieces;
+    while (!open.empty()) {
+      int n = open.back(); open.pop_back();
+      if (nodes_[n].count < kSharedNode) { pieces.push_back(n); continue; }
+      if (splitNode(n, true)) { open.push_back(nodes_[n].right); open.push_back(nodes_[n].left); }
     }
+    // the rest: independent subtrees, one thread each
+    parallelItems((int64_t)pieces.size(), [&](int64_t i, int) { buildSubtree(pieces[(size_t)i]); });
   }
 
-  void findBestBucketSplit(int n, int &bestAxis, float &bestPosition, float &bestCost) {  // BVH.cpp:72-140
-    const BuildNode &node = pool[n];
-    bestAxis = -1; bestPosition = 0; bestCost = kInf;
-    Box extent;
-    int end = node.start + node.numObjects;
-    for (int i = node.start; i < end; ++i) { extent.expand(at(i).centroid); extent.shrink(at(i).centroid); }
-    const Vec3 &maxPoint = extent.maxPoint;
-    const Vec3 &minPoint = extent.minPoint;
-    for (int axis = 0; axis < 3; ++axis) {
-      // Zero centroid extent: the reference computes scale = 16/0 = inf and (c-min)*inf = NaN, whose
-      // int conversion is undefined (INT_MIN on x86 -> out-of-bounds write and a crash; 0 on aarch64,
-      // where every candidate cost then comes out NaN and the axis is never chosen). Take the
-      // well-defined outcome: the axis offers no split.
-      if (!(maxPoint[axis] - minPoint[axis] > 0.0f)) continue;
-      Box buckets[kBuckets];
-      int bucketCount[kBuckets] = {0};
-      float scale = kBuckets / (maxPoint[axis] - minPoint[axis]);
-      for (int i = node.start; i < end; ++i) {
-        const Prim &o = at(i);
-        int bucketIdx = std::min(kBuckets - 1, static_cast<int>((o.centroid[axis] - minPoint[axis]) * scale));
-        buckets[bucketIdx].shrink(o.aabbMin);
-        buckets[bucketIdx].expand(o.aabbMax);
-        bucketCount[bucketIdx]++;
+  // pre-order numbering; returns the node count
+  int flatten(std::vector<BvhNode> &out) const {
+    out.clear();
+    std::vector<std::pair<int, int>> todo;  // (tree node, slot of the parent whose right link it fills, or -1)
+    todo.emplace_back(0, -1);
+    while (!todo.empty()) {
+      auto [n, parentSlot] = todo.back(); todo.pop_back();
+      int slot = (int)out.size();
+      if (parentSlot >= 0) out[(size_t)parentSlot].rightOrStart = slot;
+      const TreeNode &t = nodes_[(size_t)n];
+      BvhNode f{};
+      for (int k = 0; k < 3; ++k) { f.aabbMin[k] = t.box.lo[k]; f.aabbMax[k] = t.box.hi[k]; }
+      f.numObjects = t.count;
+      f.rightOrStart = t.first;
+      out.push_back(f);
+      if (t.count == 0) {  // right subtree after the whole left subtree
+        todo.emplace_back(t.right, slot);
+        todo.emplace_back(t.left, -1);
       }
-      int leftBoxCount[kBuckets - 1] = {0}, rightBoxCount[kBuckets - 1] = {0};
-      float leftBoxArea[kBuckets - 1] = {0}, rightBoxArea[kBuckets - 1] = {0};
-      int leftCount = 0, rightCount = 0;
-      Box leftBox, rightBox;
-      for (int i = 0; i < kBuckets - 1; ++i) {
-        leftCount += bucketCount[i];
-        leftBoxCount[i] = leftCount;
-        rightCount += bucketCount[kBuckets - i - 1];
-        rightBoxCount[kBuckets - i - 2] = rightCount;
-        leftBox.expand(buckets[i].maxPoint);
-        leftBox.shrink(buckets[i].minPoint);
-        leftBoxArea[i] = leftBox.surfaceArea();
-        rightBox.expand(buckets[kBuckets - i - 1].maxPoint);
-        rightBox.shrink(buckets[kBuckets - i - 1].minPoint);
-        rightBoxArea[kBuckets - i - 2] = rightBox.surfaceArea();
-      }
-      // The split plane is recomputed with a different expression than the bucket index above.
-      scale = (maxPoint[axis] - minPoint[axis]) / kBuckets;
-      for (int i = 0; i < kBuckets - 1; ++i) {
-        float cost = leftBoxArea[i] * leftBoxCount[i] + rightBoxArea[i] * rightBoxCount[i];
-        if (cost < bestCost) {
-          bestCost = cost;
-          bestAxis = axis;
-          bestPosition = minPoint[axis] + (i + 1) * scale;
+    }
+    return (int)out.size();
+  }
+
+ private:
+  struct BuildPrim { Vec3 aabbMin, aabbMax, centroid; };
+  std::vector<BuildPrim> prims_;
+  std::vector<int> order_;  // order_[i] = index into prims_ of the object at BVH position i
+  std::vector<TreeNode> nodes_;
+  std::atomic<int> used_{0};
+
+  const BuildPrim &at(int i) const { return prims_[(size_t)order_[(size_t)i]]; }
+
+  Bounds boundsOf(int first, int count, bool shared) const {  // updateNodeBounds, BVH.cpp:184-200
+    auto range = [&](int64_t b, int64_t e) {
+      Bounds r;
+      for (int64_t i = b; i < e; ++i) { const BuildPrim &o = at(first + (int)i); r.add(o.aabbMin, o.aabbMax); }
+      return r;
+    };
+    if (!shared) return range(0, count);
+    std::vector<Bounds> part((size_t)hostThreads());
+    std::atomic<int> slot{0};
+    parallelChunks(count, 1 << 14, [&](int64_t b, int64_t e) { part[(size_t)slot.fetch_add(1)] = range(b, e); });
+    Bounds r;
+    for (const Bounds &p : part) r.add(p);
+    return r;
+  }
+
+  // findBestBucketSplit, BVH.cpp:72-140, with the three axes binned in one sweep over the objects
+  Split bestSplit(const TreeNode &node, bool shared) const {
+    const int first = node.first, count = node.count;
+    // centroid extent
+    auto centroidRange = [&](int64_t b, int64_t e) {
+      Bounds r;
+      for (int64_t i = b; i < e; ++i) { const Vec3 &c = at(first + (int)i).centroid; r.add(c, c); }
+      return r;
+    };
+    Bounds ext;
+    if (shared) {
+      std::vector<Bounds> part((size_t)hostThreads());
+      std::atomic<int> slot{0};
+      parallelChunks(count, 1 << 14, [&](int64_t b, int64_t e) { part[(size_t)slot.fetch_add(1)] = centroidRange(b, e); });
+      for (const Bounds &p : part) ext.add(p);
+    } else {
+      ext = centroidRange(0, count);
+    }
+    // An axis with zero centroid extent offers no split: the reference computes scale = 16/0 = inf and
+    // (c - min) * inf = NaN there, whose int conversion is undefined (INT_MIN on x86: an out-of-bounds write; 0 on
+    // aarch64, where every candidate cost then comes out NaN and the axis is never chosen).
+    bool use[3]; float toBin[3];
+    for (int a = 0; a < 3; ++a) {
+      use[a] = ext.hi[a] - ext.lo[a] > 0.0f;
+      toBin[a] = use[a] ? kBins / (ext.hi[a] - ext.lo[a]) : 0.0f;
+    }
+    auto binRange = [&](int64_t b, int64_t e, Bins &bins) {
+      for (int64_t i = b; i < e; ++i) {
+        const BuildPrim &o = at(first + (int)i);
+        const float c[3] = {o.centroid.x, o.centroid.y, o.centroid.z};
+        for (int a = 0; a < 3; ++a) {
+          if (!use[a]) continue;
+          int k = std::min(kBins - 1, static_cast<int>((c[a] - ext.lo[a]) * toBin[a]));
+          bins.box[a][k].add(o.aabbMin, o.aabbMax);
+          bins.count[a][k]++;
         }
       }
+    };
+    Bins bins;
+    if (shared) {
+      std::vector<Bins> part((size_t)hostThreads());
+      std::atomic<int> slot{0};
+      parallelChunks(count, 1 << 14, [&](int64_t b, int64_t e) { binRange(b, e, part[(size_t)slot.fetch_add(1)]); });
+      for (const Bins &p : part) bins.add(p);
+    } else {
+      binRange(0, count, bins);
     }
-  }
-
-  int partition(int n) {  // BVH.cpp:231-281; returns the node count of the subtree
-    if (pool[n].numObjects <= kMinLeafSize) return 1;
-    int axis; float splitPosition, bestCost;
-    findBestBucketSplit(n, axis, splitPosition, bestCost);
-    Box parentBox; parentBox.minPoint = pool[n].aabbMin; parentBox.maxPoint = pool[n].aabbMax;
-    float parentCost = parentBox.surfaceArea() * pool[n].numObjects;
-    if (bestCost >= parentCost) return 1;
-    int i = pool[n].start;
-    int j = i + pool[n].numObjects;
-    // Same algorithm object as the reference: libstdc++'s std::partition on random-access iterators.
-    // It is not stable; the resulting order is part of the contract.
-    auto middle = std::partition(order.begin() + i, order.begin() + j,
-                                 [&](int idx) { return prims[idx].centroid[axis] < splitPosition; });
-    int leftNumObjects = (int)std::distance(order.begin() + i, middle);
-    if (leftNumObjects == 0 || leftNumObjects == pool[n].numObjects) return 1;
-    int l = (int)pool.size(); pool.emplace_back();
-    int r = (int)pool.size(); pool.emplace_back();
-    pool[l].start = pool[n].start; pool[l].numObjects = leftNumObjects;
-    pool[r].start = i + leftNumObjects; pool[r].numObjects = pool[n].numObjects - leftNumObjects;
-    pool[n].left = l; pool[n].right = r; pool[n].numObjects = 0;
-    updateNodeBounds(l);
-    updateNodeBounds(r);
-    int nl = partition(l);
-    int nr = partition(r);
-    return nl + nr + 1;
-  }
-
-  void flatten(int n, std::vector<BvhNode> &out) {  // BVH.cpp:411-428 (iterative pre-order DFS)
-    struct Frame { int node; int slot; int stage; };
-    std::vector<Frame> stack;
-    stack.push_back({n, -1, 0});
-    while (!stack.empty()) {
-      Frame &f = stack.back();
-      const BuildNode &b = pool[f.node];
-      if (f.stage == 0) {
-        f.slot = (int)out.size();
-        BvhNode fn{};
-        fn.aabbMin[0] = b.aabbMin.x; fn.aabbMin[1] = b.aabbMin.y; fn.aabbMin[2] = b.aabbMin.z;
-        fn.aabbMax[0] = b.aabbMax.x; fn.aabbMax[1] = b.aabbMax.y; fn.aabbMax[2] = b.aabbMax.z;
-        fn.numObjects = b.numObjects;
-        fn.rightOrStart = b.start;
-        out.push_back(fn);
-        if (b.numObjects > 0) { stack.pop_back(); continue; }
-        f.stage = 1;
-        int left = b.left;
-        stack.push_back({left, -1, 0});
-      } else if (f.stage == 1) {
-        out[f.slot].rightOrStart = (int)out.size();
-        f.stage = 2;
-        int right = b.right;
-        stack.push_back({right, -1, 0});
-      } else {
-        stack.pop_back();
+    Split best;
+    for (int a = 0; a < 3; ++a) {
+      if (!use[a]) continue;
+      // areas and counts left / right of each of the 15 planes
+      float areaL[kBins - 1], areaR[kBins - 1];
+      int countL[kBins - 1], countR[kBins - 1];
+      Bounds l, r;
+      int nl = 0, nr = 0;
+      for (int i = 0; i < kBins - 1; ++i) {
+        nl += bins.count[a][i]; countL[i] = nl;
+        nr += bins.count[a][kBins - 1 - i]; countR[kBins - 2 - i] = nr;
+        l.add(bins.box[a][i]); areaL[i] = l.area();
+        r.add(bins.box[a][kBins - 1 - i]); areaR[kBins - 2 - i] = r.area();
       }
+      // the plane position uses extent/16, not the reciprocal of the binning factor (BVH.cpp:127, 134)
+      float width = (ext.hi[a] - ext.lo[a]) / kBins;
+      for (int i = 0; i < kBins - 1; ++i) {
+        float cost = areaL[i] * countL[i] + areaR[i] * countR[i];
+        if (cost < best.cost) { best.cost = cost; best.axis = a; best.position = ext.lo[a] + (i + 1) * width; }
+      }
+    }
+    return best;
+  }
+
+  // One step of BVH::partition (BVH.cpp:231-281): false = n stays a leaf.
+  bool splitNode(int n, bool shared) {
+    TreeNode &node = nodes_[(size_t)n];
+    if (node.count <= kLeafObjects) return false;
+    Split s = bestSplit(node, shared);
+    if (s.cost >= node.box.area() * node.count) return false;
+    // The reference regroups with libstdc++'s std::partition on random-access iterators; it is not stable, and the
+    // order it leaves is part of the contract, so the same algorithm object is used.
+    auto lo = order_.begin() + node.first, hi = lo + node.count;
+    const int axis = s.axis; const float pos = s.position;
+    auto mid = std::partition(lo, hi, [&](int idx) { return prims_[(size_t)idx].centroid[axis] < pos; });
+    int nLeft = (int)(mid - lo);
+    if (nLeft == 0 || nLeft == node.count) return false;
+    int l = used_.fetch_add(2), r = l + 1;
+    nodes_[(size_t)l].first = node.first; nodes_[(size_t)l].count = nLeft;
+    nodes_[(size_t)r].first = node.first + nLeft; nodes_[(size_t)r].count = node.count - nLeft;
+    nodes_[(size_t)l].box = boundsOf(nodes_[(size_t)l].first, nodes_[(size_t)l].count, shared);
+    nodes_[(size_t)r].box = boundsOf(nodes_[(size_t)r].first, nodes_[(size_t)r].count, shared);
+    node.left = l; node.right = r; node.count = 0;
+    return true;
+  }
+
+  void buildSubtree(int root) {
+    std::vector<int> open{root};
+    while (!open.empty()) {
+      int n = open.back(); open.pop_back();
+      if (splitNode(n, false)) { open.push_back(nodes_[(size_t)n].right); open.push_back(nodes_[(size_t)n].left); }
     }
   }
 };
@@ -180,18 +241,15 @@ void buildBVH(Scene &scene) {
     scene.log.push_back("No triangles or spheres in scene. BVH not created.");
     return;
   }
-  Builder b(scene.prims);
-  b.pool.reserve(scene.prims.size() * 2 + 1);
-  b.pool.emplace_back();
-  b.pool[0].start = 0;
-  b.pool[0].numObjects = (int)scene.prims.size();
-  b.updateNodeBounds(0);
-  int numNodes = b.partition(0);
-  scene.nodes.reserve(numNodes);
-  b.flatten(0, scene.nodes);
-  std::vector<Prim> reordered;
-  reordered.reserve(scene.prims.size());
-  for (int idx : b.order) reordered.push_back(scene.prims[idx]);
+  TreeBuilder tb(scene.prims);
+  tb.build();
+  int numNodes = tb.flatten(scene.nodes);
+  // Scene::objects end up in leaf order (BVH.cpp:258 reorders them in place)
+  std::vector<Prim> reordered(scene.prims.size());
+  const std::vector<int> &order = tb.order();
+  parallelChunks((int64_t)order.size(), 1 << 14, [&](int64_t b, int64_t e) {
+    for (int64_t i = b; i < e; ++i) reordered[(size_t)i] = scene.prims[(size_t)order[(size_t)i]];
+  });
   scene.prims.swap(reordered);
   scene.log.push_back("BVH created with " + std::to_string(numNodes) + " nodes on " +
                       std::to_string(scene.prims.size()) + " objects.");

@@ -6,6 +6,7 @@
 
 #include "rt_host.h"
 #include "rth_scene.h"
+#include "rth_threads.h"
 
 using namespace rth;
 
@@ -23,6 +24,9 @@ Color c4(const float *p) { return Color(p[0], p[1], p[2], p[3]); }
 }  // namespace
 
 extern "C" {
+
+void rth_set_threads(int32_t n) { rth::setHostThreads(n); }
+int32_t rth_get_threads(void) { return rth::hostThreads(); }
 
 const char *rth_last_error(void) { return g_error.c_str(); }
 
@@ -101,17 +105,22 @@ int rth_scene_add_mesh(RthScene *h, int64_t numVerts, const float *vertices, con
   Vec3 shift = v3(center) - (extMax + extMin) / 2;
   float scaleFactor = scale / maxDimension(extMax - extMin);
   Color col = c4(color);
-  h->scene->prims.reserve(h->scene->prims.size() + (size_t)numTris);
-  for (int64_t t = 0; t < numTris; ++t) {
-    int32_t i = indices[t * 3], j = indices[t * 3 + 1], k = indices[t * 3 + 2];
-    if (i < 0 || j < 0 || k < 0 || i >= numVerts || j >= numVerts || k >= numVerts) return fail("mesh index out of range");
-    Prim tri = makeTriangle(scaleFactor * v3(vertices + 3 * (int64_t)i) + shift, scaleFactor * v3(vertices + 3 * (int64_t)j) + shift,
-                            scaleFactor * v3(vertices + 3 * (int64_t)k) + shift, col, material);
-    if (normals) {
-      tri.n1 = v3(normals + 3 * (int64_t)i); tri.n2 = v3(normals + 3 * (int64_t)j); tri.n3 = v3(normals + 3 * (int64_t)k);
+  for (int64_t t = 0; t < numTris * 3; ++t)
+    if (indices[t] < 0 || indices[t] >= numVerts) return fail("mesh index out of range");
+  std::vector<Prim> tris((size_t)numTris);
+  parallelChunks(numTris, 1 << 12, [&](int64_t b, int64_t e) {  // triangle set-up is independent per triangle
+    for (int64_t t = b; t < e; ++t) {
+      int32_t i = indices[t * 3], j = indices[t * 3 + 1], k = indices[t * 3 + 2];
+      Prim tri = makeTriangle(scaleFactor * v3(vertices + 3 * (int64_t)i) + shift, scaleFactor * v3(vertices + 3 * (int64_t)j) + shift,
+                              scaleFactor * v3(vertices + 3 * (int64_t)k) + shift, col, material);
+      if (normals) {
+        tri.n1 = v3(normals + 3 * (int64_t)i); tri.n2 = v3(normals + 3 * (int64_t)j); tri.n3 = v3(normals + 3 * (int64_t)k);
+      }
+      tris[(size_t)t] = tri;
     }
-    h->scene->addPrim(tri);
-  }
+  });
+  h->scene->prims.reserve(h->scene->prims.size() + (size_t)numTris);
+  for (const Prim &tri : tris) h->scene->addPrim(tri);  // in order: the centroid sum is a float sum
   h->built = false;
   return RT_OK;
 }

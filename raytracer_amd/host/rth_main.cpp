@@ -11,7 +11,7 @@
 //   --seed N        seed of the counter-based random stream (default 56, the reference's unused `seed` default)
 //   --dump-hits F   write primary-ray hit ids and t (int32, float32 per pixel, row-major) to F and exit
 //   --stats         print ray counts, Mrays/s and per-kernel milliseconds
-// `-t` keeps meaning host threads; the GPU path has no use for it beyond accepting it.
+// `-t` keeps meaning host threads: it sets how many the parsers and the BVH build use (default: all, at most 16).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -48,7 +48,7 @@ int usage(const char *argv0, int code) {
 }  // namespace
 
 int main(int argc, char **argv) {
-  int numThreads = 4;
+  int numThreads = 0;  // 0 = not given: the host library picks (the reference's default of 4 is a CPU-render setting)
   int gpus = 1, tileW = 32, tileH = 32, sppPass = 0;
   unsigned seed = 56;
   bool stats = false;
@@ -70,8 +70,8 @@ int main(int argc, char **argv) {
     else if (!a.empty() && a[0] == '-') return usage(argv[0], -1);
     else path = a;
   }
-  (void)numThreads;
   if (path.empty()) return usage(argv[0], 1);
+  if (numThreads > 0) rth_set_threads(numThreads);  // host threads: parsing, triangle set-up, BVH build
   if (gpus < 1) gpus = 1;
 
   std::vector<Phase> phases;

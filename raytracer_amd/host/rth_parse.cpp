@@ -2,6 +2,9 @@
 // .sdml format (src/parser/ParserTree.cpp) and the Wavefront OBJ loader (src/parser/parser.cpp:47-142).
 // They run once per render on the host; what matters is that they produce the same floats, the same
 // object order and the same quirks (normal flips toward the camera, lights parsed last, OBJ recentring).
+#include <cerrno>
+#include <climits>
+#include <cstring>
 #include <fstream>
 #include <functional>
 #include <sstream>
@@ -9,6 +12,7 @@
 #include <unordered_map>
 
 #include "rth_scene.h"
+#include "rth_threads.h"
 
 namespace rth {
 namespace {
@@ -27,15 +31,6 @@ std::vector<std::string> split(const std::string &s, char delim) {
 
 bool endsWith(const std::string &value, const std::string &ending) {
   return ending.size() <= value.size() && std::equal(ending.rbegin(), ending.rend(), value.rbegin());
-}
-
-// parser.cpp:33-45 — "a/b/c", "a//c" (missing fields become -1)
-std::vector<int> parseOBJPoint(const std::string &s) {
-  std::vector<int> indices;
-  std::istringstream iss(s);
-  std::string item;
-  while (std::getline(iss, item, '/')) indices.push_back(item.empty() ? -1 : std::stoi(item));
-  return indices;
 }
 
 std::string trimCopy(std::string s) {
@@ -462,59 +457,163 @@ std::unique_ptr<Scene> readSdml(std::istream &in, std::string &error) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------- OBJ meshes
+// What the reference's loadOBJ accepts and produces (src/parser/parser.cpp:47-142), read differently: the file is
+// loaded once, scanned for `v` / `vn` lines and then for `f` lines (faces may name vertices that come later in the file,
+// as with the reference's two passes), numbers go through strtof / strtol (what std::stof / std::stoi call), and the
+// triangles (double-precision constants per triangle) are set up by all host threads.
+// Kept behaviours: only ' ' separates fields (a tab is part of a field); empty fields are dropped; extra fields are
+// ignored; a malformed or missing number is an error (the reference aborts on the uncaught exception); `a/b/c` and
+// `a//c` take normals, without transforming or normalising them, only when the FIRST corner has three fields;
+// polygons are fanned; a corner index beyond the vertex list skips the triangle with a message; index 0 or a
+// negative index is an error (out-of-range `at()` in the reference); vertices are recentred on the bounding-box
+// centre and scaled by the largest extent (parser.cpp:93-94).
+namespace {
+
+struct Field { const char *p; size_t n; };
+
+// fields of the line [b, e), separated by single spaces, empty ones dropped
+inline void fieldsOf(const char *b, const char *e, std::vector<Field> &out) {
+  out.clear();
+  while (b < e) {
+    const char *q = static_cast<const char *>(std::memchr(b, ' ', (size_t)(e - b)));
+    if (!q) q = e;
+    if (q > b) out.push_back({b, (size_t)(q - b)});
+    b = q + 1;
+  }
+}
+
+inline bool isField(const Field &f, const char *word) { return std::strlen(word) == f.n && std::memcmp(f.p, word, f.n) == 0; }
+
+// std::stof on the field: the buffer is NUL-terminated and a field ends at ' ' or '\n', where strtof stops too
+float fieldFloat(const std::vector<Field> &f, size_t i) {
+  if (i >= f.size()) throw std::out_of_range("vector::_M_range_check");
+  char *end = nullptr;
+  errno = 0;
+  float v = std::strtof(f[i].p, &end);
+  if (end == f[i].p || end > f[i].p + f[i].n) throw std::invalid_argument("stof");
+  if (errno == ERANGE) throw std::out_of_range("stof");
+  return v;
+}
+
+// one corner "a", "a/b", "a//c", "a/b/c": up to three integers, -1 for an empty one; returns how many there are
+int cornerOf(const Field &f, int out[3]) {
+  const char *b = f.p, *e = f.p + f.n;
+  int n = 0;
+  while (b < e) {  // std::getline(iss, item, '/') yields no trailing empty item
+    const char *q = static_cast<const char *>(std::memchr(b, '/', (size_t)(e - b)));
+    if (!q) q = e;
+    int v = -1;
+    if (q > b) {
+      char *end = nullptr;
+      errno = 0;
+      long l = std::strtol(b, &end, 10);
+      if (end == b || end > q) throw std::invalid_argument("stoi");
+      if (errno == ERANGE || l < INT_MIN || l > INT_MAX) throw std::out_of_range("stoi");
+      v = (int)l;
+    }
+    if (n < 3) out[n] = v;
+    ++n;
+    b = q + 1;
+  }
+  return n;
+}
+
+struct Face { int v[3]; int n[3]; bool withNormals; };
+
+}  // namespace
+
 bool loadOBJ(const Vec3 &center, float scale, const std::string &filename, Scene &scene, const Color &color,
              int material, std::string &error) {
-  std::ifstream infile(filename);
-  if (!infile) { error = "Couldn't open file " + filename; return false; }
+  std::string text;
+  {
+    std::ifstream infile(filename, std::ios::binary);
+    if (!infile) { error = "Couldn't open file " + filename; return false; }
+    infile.seekg(0, std::ios::end);
+    std::streamoff size = infile.tellg();
+    infile.seekg(0, std::ios::beg);
+    text.resize((size_t)std::max<std::streamoff>(0, size));
+    infile.read(text.data(), (std::streamsize)text.size());
+    text.resize((size_t)infile.gcount());
+  }
+  const char *base = text.c_str(), *stop = base + text.size();
+  auto eachLine = [&](auto &&fn) {
+    for (const char *b = base; b < stop;) {
+      const char *e = static_cast<const char *>(std::memchr(b, '\n', (size_t)(stop - b)));
+      if (!e) e = stop;
+      fn(b, e);
+      b = e + 1;
+    }
+  };
   std::vector<Vec3> points, normals;
   Vec3 extMin(kInf, kInf, kInf), extMax(-kInf, -kInf, -kInf);
-  std::vector<std::string> info;
-  for (std::string line; std::getline(infile, line);) {
-    info = split(line, ' ');
-    if (info.empty()) continue;
-    const std::string &keyword = info[0];
-    if (keyword == "v") {
-      float x = std::stof(info.at(1)), y = std::stof(info.at(2)), z = std::stof(info.at(3));
+  std::vector<Field> f;
+  eachLine([&](const char *b, const char *e) {
+    while (b < e && *b == ' ') ++b;
+    if (b == e || *b != 'v') return;  // only `v` and `vn` lines matter here
+    fieldsOf(b, e, f);
+    if (f.empty()) return;
+    if (isField(f[0], "v")) {
+      float x = fieldFloat(f, 1), y = fieldFloat(f, 2), z = fieldFloat(f, 3);
       extMin = Vec3(std::min(extMin.x, x), std::min(extMin.y, y), std::min(extMin.z, z));
       extMax = Vec3(std::max(extMax.x, x), std::max(extMax.y, y), std::max(extMax.z, z));
       points.emplace_back(x, y, z);
-    } else if (keyword == "vn") {
-      normals.emplace_back(std::stof(info.at(1)), std::stof(info.at(2)), std::stof(info.at(3)));
+    } else if (isField(f[0], "vn")) {
+      float x = fieldFloat(f, 1), y = fieldFloat(f, 2), z = fieldFloat(f, 3);
+      normals.emplace_back(x, y, z);
     }
-  }
-  // parser.cpp:93-94
-  Vec3 shift = center - (extMax + extMin) / 2;
-  float scaleFactor = scale / maxDimension(extMax - extMin);
-  int numObjects = 0;
-  int numPoints = (int)points.size();
-  infile = std::ifstream(filename);  // second pass over the file, faces only (parser.cpp:96-138)
-  for (std::string line; std::getline(infile, line);) {
-    info = split(line, ' ');
-    if (info.empty() || info[0] != "f") continue;
-    std::vector<int> vertex1 = parseOBJPoint(info.at(1));
-    int i = vertex1.at(0) - 1;
-    for (size_t idx = 2; idx + 1 < info.size(); ++idx) {  // triangle fan
-      std::vector<int> vertex2 = parseOBJPoint(info.at(idx));
-      std::vector<int> vertex3 = parseOBJPoint(info.at(idx + 1));
-      int j = vertex2.at(0) - 1, k = vertex3.at(0) - 1;
+  });
+  const int numPoints = (int)points.size();
+  std::vector<Face> faces;
+  std::vector<std::string> skipped;
+  eachLine([&](const char *b, const char *e) {
+    while (b < e && *b == ' ') ++b;
+    if (b == e || *b != 'f') return;
+    fieldsOf(b, e, f);
+    if (f.empty() || !isField(f[0], "f")) return;
+    if (f.size() < 2) throw std::out_of_range("vector::_M_range_check");
+    int c1[3] = {-1, -1, -1}, c2[3], c3[3];
+    const int n1 = cornerOf(f[1], c1);
+    if (n1 < 1) throw std::out_of_range("vector::_M_range_check");
+    for (size_t idx = 2; idx + 1 < f.size(); ++idx) {  // triangle fan around the first corner
+      c2[0] = c2[1] = c2[2] = c3[0] = c3[1] = c3[2] = -1;
+      const int n2 = cornerOf(f[idx], c2), n3 = cornerOf(f[idx + 1], c3);
+      if (n2 < 1 || n3 < 1) throw std::out_of_range("vector::_M_range_check");
+      const int i = c1[0] - 1, j = c2[0] - 1, k = c3[0] - 1;
       if (i >= numPoints || j >= numPoints || k >= numPoints) {
-        scene.log.push_back("Indices out of range: " + std::to_string(i) + ' ' + std::to_string(j) + ' ' + std::to_string(k));
+        skipped.push_back("Indices out of range: " + std::to_string(i) + ' ' + std::to_string(j) + ' ' + std::to_string(k));
         continue;
       }
-      Vec3 v1 = scaleFactor * points.at(i) + shift;
-      Vec3 v2 = scaleFactor * points.at(j) + shift;
-      Vec3 v3 = scaleFactor * points.at(k) + shift;
-      Prim t = makeTriangle(v1, v2, v3, color, material);
-      if (vertex1.size() == 3) {  // normals are taken as they are: not transformed, not normalised
-        t.n1 = normals.at(vertex1.at(2) - 1);
-        t.n2 = normals.at(vertex2.at(2) - 1);
-        t.n3 = normals.at(vertex3.at(2) - 1);
+      if (i < 0 || j < 0 || k < 0) throw std::out_of_range("vector::_M_range_check");
+      Face face{{i, j, k}, {0, 0, 0}, n1 == 3};
+      if (face.withNormals) {
+        if (n2 < 3 || n3 < 3) throw std::out_of_range("vector::_M_range_check");
+        const int a = c1[2] - 1, bb = c2[2] - 1, c = c3[2] - 1, nn = (int)normals.size();
+        if (a < 0 || bb < 0 || c < 0 || a >= nn || bb >= nn || c >= nn) throw std::out_of_range("vector::_M_range_check");
+        face.n[0] = a; face.n[1] = bb; face.n[2] = c;
       }
-      scene.addPrim(t);
-      ++numObjects;
+      faces.push_back(face);
     }
-  }
-  scene.log.push_back("Scanned " + std::to_string(points.size()) + " points and " + std::to_string(numObjects) + " objects");
+  });
+  for (std::string &m : skipped) scene.log.push_back(std::move(m));
+  // parser.cpp:93-94
+  const Vec3 shift = center - (extMax + extMin) / 2;
+  const float scaleFactor = scale / maxDimension(extMax - extMin);
+  std::vector<Prim> tris(faces.size());
+  parallelChunks((int64_t)faces.size(), 1 << 12, [&](int64_t b, int64_t e) {
+    for (int64_t t = b; t < e; ++t) {
+      const Face &fc = faces[(size_t)t];
+      Prim p = makeTriangle(scaleFactor * points[(size_t)fc.v[0]] + shift, scaleFactor * points[(size_t)fc.v[1]] + shift,
+                            scaleFactor * points[(size_t)fc.v[2]] + shift, color, material);
+      if (fc.withNormals) {
+        p.n1 = normals[(size_t)fc.n[0]]; p.n2 = normals[(size_t)fc.n[1]]; p.n3 = normals[(size_t)fc.n[2]];
+      }
+      tris[(size_t)t] = p;
+    }
+  });
+  scene.prims.reserve(scene.prims.size() + tris.size());
+  for (const Prim &p : tris) scene.addPrim(p);  // in file order: the centroid sum is a float sum
+  scene.log.push_back("Scanned " + std::to_string(points.size()) + " points and " + std::to_string(faces.size()) + " objects");
   return true;
 }
 

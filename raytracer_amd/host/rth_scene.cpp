@@ -1,4 +1,5 @@
 #include "rth_scene.h"
+#include "rth_threads.h"
 
 #include <algorithm>
 #include <cstring>
@@ -178,4 +179,18 @@ bool flatten(const Scene &scene, FlatScene &out, std::string &error) {
   return true;
 }
 
+}  // namespace rth
+
+// ---- host worker threads (rth_threads.h)
+namespace rth {
+namespace {
+std::atomic<int> g_hostThreads{0};
+}
+int hostThreads() {
+  int n = g_hostThreads.load();
+  if (n > 0) return n;
+  unsigned hw = std::thread::hardware_concurrency();
+  return (int)std::max(1u, std::min(16u, hw ? hw : 1u));
+}
+void setHostThreads(int n) { g_hostThreads.store(n > 0 ? std::min(n, 256) : 0); }
 }  // namespace rth

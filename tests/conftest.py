@@ -13,7 +13,7 @@ from tools import gen_scenes  # noqa: E402
 GOLDEN = os.path.join(REPO, "tests", "golden")
 SCENE_EXT = {"spheres_txt": "txt", "spheres_txt_dof": "txt", "spheres_txt_fisheye": "txt"}
 SMALL_SCENES = ["config1", "config1_rngfree", "materials", "mesh1k", "mesh1k_gi", "spheres_txt", "spheres_txt_dof",
-                "spheres_txt_fisheye", "readme_small"]
+                "spheres_txt_fisheye", "readme_small", "obj_quirks"]
 
 
 def pytest_configure(config):

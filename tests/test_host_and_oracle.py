@@ -132,6 +132,41 @@ def test_scene_errors(tmp_path):
         capi.HostScene.load(str(p)).build()
 
 
+@pytest.mark.parametrize("body,needle", [
+    ("v 0 0 0\nv 1 0\nv 0 1 0\nf 1 2 3\n", "malformed"),          # a coordinate is missing
+    ("v 0 0 0\nv 1 x 0\nv 0 1 0\nf 1 2 3\n", "malformed"),        # not a number
+    ("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 q\n", "malformed"),        # not an index
+    ("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 0 1 2\n", "malformed"),        # index 0 (the reference's at(-1) throws)
+    ("v 0 0 0\nv 1 0 0\nv 0 1 0\nf -1 -2 -3\n", "malformed"),     # negative indices are not supported
+    ("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1//1 2//2 3//3\n", "malformed"),  # normals named but none given
+    ("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1//1 2 3\nvn 0 0 1\n", "malformed"),  # first corner has a normal, the others do not
+    ("v 1e-60 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n", "malformed"),    # std::stof reports underflow as out of range
+])
+def test_obj_loader_rejects_what_the_reference_aborts_on(tmp_path, body, needle):
+    """Where the reference dies on an uncaught std::stof / std::stoi / at() exception (src/parser/parser.cpp:47-142),
+    the host library returns an error."""
+    (tmp_path / "m.obj").write_text(body)
+    (tmp_path / "s.sdml").write_text(
+        "<Scene options={width: 8; height: 8; filename: o.png}>\n  <Camera options={}/>\n"
+        f"  <Wavefront path=\"{tmp_path / 'm.obj'}\" options={{center: (0, 0, -3); scale: 1}}>\n  </Wavefront>\n</Scene>\n")
+    with pytest.raises(RuntimeError, match=needle):
+        capi.HostScene.load(str(tmp_path / "s.sdml"))
+
+
+def test_host_thread_count_never_changes_the_result(scene_path):
+    """Parsing, triangle set-up and the BVH build give the same bytes with 1 and with many host threads."""
+    out = []
+    for n in (1, 7):
+        capi.set_host_threads(n)
+        assert capi.host_threads() == n
+        hs = capi.HostScene.load(scene_path("readme_mid")).build()
+        d = hs.desc.contents
+        hit = np.ctypeslib.as_array(d.primHit, shape=(d.numPrims * 12,)).copy()
+        out.append((sha1(hs.nodes()), sha1(hs.prim_orig_index()), sha1(hit)))
+    capi.set_host_threads(0)
+    assert out[0] == out[1]
+
+
 def test_empty_scene_and_planes_only(tmp_path):
     p = tmp_path / "empty.txt"; p.write_text("png 8 8 a.png\n")
     hs = capi.HostScene.load(str(p)).build()
