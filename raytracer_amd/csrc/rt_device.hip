@@ -917,7 +917,7 @@ int ensureRenderBuffers(RtScene *s, int64_t P, int64_t npix, int64_t fbPixels) {
   }
   if (s->arenaP < P) {
     if (s->arena) (void)hipFree(s->arena);
-    s->arena = nullptr;
+    s->arena = nullptr; s->arenaP = 0; s->arenaBytes = 0;
     int64_t nEnv = std::max(1, s->numEnvLights);
     int64_t nLights = std::max(1, s->dev.numLights);
     size_t bytes = (size_t)P * (sizeof(float4) * (7 + nEnv + nLights) + 4 * 6) + 4096;
@@ -1141,10 +1141,21 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
     const size_t perPath = sizeof(float4) * (7 + std::max(1, s->numEnvLights) + std::max(1, s->dev.numLights)) + 4 * 6;
     sppPass = (int)std::min<size_t>((size_t)S.numRays, std::max<size_t>(1, budget / (perPath * (size_t)std::max<int64_t>(1, npix))));
   }
+  const bool sppPassChosenHere = params->samplesPerPass <= 0;
   sppPass = std::min(sppPass, S.numRays);
+  if (sppPassChosenHere)  // path slots are 31-bit indices
+    sppPass = (int)std::max<int64_t>(1, std::min<int64_t>(sppPass, (((int64_t)1 << 31) - 1) / std::max<int64_t>(1, npix)));
   int64_t P = std::max<int64_t>(1, npix * sppPass);
   if (P >= ((int64_t)1 << 31)) return failMsg(RT_ERR_INVALID, "samplesPerPass too large for this image");
   int rc = ensureRenderBuffers(s, P, std::max<int64_t>(1, npix), fbPixels);
+  // Somebody else may have taken the memory between the query and the allocation: with a pass size chosen here, fall
+  // back to smaller passes instead of failing the frame.
+  while (rc == RT_ERR_DEVICE && sppPassChosenHere && sppPass > 1) {
+    (void)hipGetLastError();
+    sppPass = std::max(1, sppPass / 2);
+    P = std::max<int64_t>(1, npix * sppPass);
+    rc = ensureRenderBuffers(s, P, std::max<int64_t>(1, npix), fbPixels);
+  }
   if (rc) return rc;
   PathBuf B = s->buf;
   bool timing = stats != nullptr;
