@@ -58,7 +58,7 @@ class TreeBuilder {
  public:
   explicit TreeBuilder(const std::vector<Prim> &p) : prims_(p.size()), order_(p.size()), nodes_(2 * p.size() + 1) {
     // the build only looks at boxes and centroids: 36 bytes per object instead of the whole record
-    parallelChunks((int64_t)p.size(), 1 << 14, [&](int64_t b, int64_t e) {
+    parallelChunks((int64_t)p.size(), 1 << 14, [&](int64_t b, int64_t e, int) {
       for (int64_t i = b; i < e; ++i) {
         const Prim &o = p[(size_t)i];
         prims_[(size_t)i] = BuildPrim{o.aabbMin, o.aabbMax, o.centroid};
@@ -122,9 +122,9 @@ class TreeBuilder {
       return r;
     };
     if (!shared) return range(0, count);
+    // partial results are combined in data order: min / max keep the first of two equal values, and -0 == +0
     std::vector<Bounds> part((size_t)hostThreads());
-    std::atomic<int> slot{0};
-    parallelChunks(count, 1 << 14, [&](int64_t b, int64_t e) { part[(size_t)slot.fetch_add(1)] = range(b, e); });
+    parallelChunks(count, 1 << 14, [&](int64_t b, int64_t e, int chunk) { part[(size_t)chunk] = range(b, e); });
     Bounds r;
     for (const Bounds &p : part) r.add(p);
     return r;
@@ -142,8 +142,7 @@ class TreeBuilder {
     Bounds ext;
     if (shared) {
       std::vector<Bounds> part((size_t)hostThreads());
-      std::atomic<int> slot{0};
-      parallelChunks(count, 1 << 14, [&](int64_t b, int64_t e) { part[(size_t)slot.fetch_add(1)] = centroidRange(b, e); });
+      parallelChunks(count, 1 << 14, [&](int64_t b, int64_t e, int chunk) { part[(size_t)chunk] = centroidRange(b, e); });
       for (const Bounds &p : part) ext.add(p);
     } else {
       ext = centroidRange(0, count);
@@ -171,8 +170,7 @@ class TreeBuilder {
     Bins bins;
     if (shared) {
       std::vector<Bins> part((size_t)hostThreads());
-      std::atomic<int> slot{0};
-      parallelChunks(count, 1 << 14, [&](int64_t b, int64_t e) { binRange(b, e, part[(size_t)slot.fetch_add(1)]); });
+      parallelChunks(count, 1 << 14, [&](int64_t b, int64_t e, int chunk) { binRange(b, e, part[(size_t)chunk]); });
       for (const Bins &p : part) bins.add(p);
     } else {
       binRange(0, count, bins);
@@ -247,7 +245,7 @@ void buildBVH(Scene &scene) {
   // Scene::objects end up in leaf order (BVH.cpp:258 reorders them in place)
   std::vector<Prim> reordered(scene.prims.size());
   const std::vector<int> &order = tb.order();
-  parallelChunks((int64_t)order.size(), 1 << 14, [&](int64_t b, int64_t e) {
+  parallelChunks((int64_t)order.size(), 1 << 14, [&](int64_t b, int64_t e, int) {
     for (int64_t i = b; i < e; ++i) reordered[(size_t)i] = scene.prims[(size_t)order[(size_t)i]];
   });
   scene.prims.swap(reordered);

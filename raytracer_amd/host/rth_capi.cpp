@@ -108,7 +108,7 @@ int rth_scene_add_mesh(RthScene *h, int64_t numVerts, const float *vertices, con
   for (int64_t t = 0; t < numTris * 3; ++t)
     if (indices[t] < 0 || indices[t] >= numVerts) return fail("mesh index out of range");
   std::vector<Prim> tris((size_t)numTris);
-  parallelChunks(numTris, 1 << 12, [&](int64_t b, int64_t e) {  // triangle set-up is independent per triangle
+  parallelChunks(numTris, 1 << 12, [&](int64_t b, int64_t e, int) {  // triangle set-up is independent per triangle
     for (int64_t t = b; t < e; ++t) {
       int32_t i = indices[t * 3], j = indices[t * 3 + 1], k = indices[t * 3 + 2];
       Prim tri = makeTriangle(scaleFactor * v3(vertices + 3 * (int64_t)i) + shift, scaleFactor * v3(vertices + 3 * (int64_t)j) + shift,

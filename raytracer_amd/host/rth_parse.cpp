@@ -600,7 +600,7 @@ bool loadOBJ(const Vec3 &center, float scale, const std::string &filename, Scene
   const Vec3 shift = center - (extMax + extMin) / 2;
   const float scaleFactor = scale / maxDimension(extMax - extMin);
   std::vector<Prim> tris(faces.size());
-  parallelChunks((int64_t)faces.size(), 1 << 12, [&](int64_t b, int64_t e) {
+  parallelChunks((int64_t)faces.size(), 1 << 12, [&](int64_t b, int64_t e, int) {
     for (int64_t t = b; t < e; ++t) {
       const Face &fc = faces[(size_t)t];
       Prim p = makeTriangle(scaleFactor * points[(size_t)fc.v[0]] + shift, scaleFactor * points[(size_t)fc.v[1]] + shift,

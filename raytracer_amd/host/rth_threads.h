@@ -13,17 +13,19 @@ namespace rth {
 int hostThreads();          // current setting (default: hardware threads, at most 16)
 void setHostThreads(int n); // n <= 0 restores the default
 
-// fn(begin, end) over [0, n) in contiguous chunks of at least `grain` items, one chunk per worker.
+// fn(begin, end, chunk) over [0, n) in contiguous chunks of at least `grain` items, one chunk per worker; `chunk`
+// counts the chunks in index order (0 .. at most hostThreads() - 1), so per-chunk partial results can be combined in
+// the order of the data.
 template <class F>
 void parallelChunks(int64_t n, int64_t grain, F fn) {
   int workers = (int)std::min<int64_t>(hostThreads(), std::max<int64_t>(1, n / std::max<int64_t>(1, grain)));
-  if (workers <= 1) { fn((int64_t)0, n); return; }
+  if (workers <= 1) { fn((int64_t)0, n, 0); return; }
   std::vector<std::thread> pool;
   int64_t per = (n + workers - 1) / workers;
   for (int w = 0; w < workers; ++w) {
     int64_t b = w * per, e = std::min(n, b + per);
     if (b >= e) break;
-    pool.emplace_back([=]() { fn(b, e); });
+    pool.emplace_back([=]() { fn(b, e, w); });
   }
   for (auto &t : pool) t.join();
 }
