@@ -1051,16 +1051,19 @@ int rt_trace_primary(RtScene *s, int32_t x0, int32_t y0, int32_t w, int32_t h, i
   int64_t n = (int64_t)w * h;
   int32_t *dPrim = nullptr;
   float *dT = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dPrim), n * 4));
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dT), n * 4));
-  int64_t waves = (int64_t)((w + 7) / 8) * ((h + 7) / 8);
-  k_reset_trace_ticket<<<1, 1, 0, s->stream>>>(s->counts);
-  k_trace_primary<<<persistentGrid(s, waves * 64), kBlock, 0, s->stream>>>(s->dev, x0, y0, w, h, dPrim, dT, s->counts);
-  hipError_t e = hipGetLastError();
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&dPrim), n * 4);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dT), n * 4);
+  if (e == hipSuccess) {
+    int64_t waves = (int64_t)((w + 7) / 8) * ((h + 7) / 8);
+    k_reset_trace_ticket<<<1, 1, 0, s->stream>>>(s->counts);
+    k_trace_primary<<<persistentGrid(s, waves * 64), kBlock, 0, s->stream>>>(s->dev, x0, y0, w, h, dPrim, dT, s->counts);
+    e = hipGetLastError();
+  }
   if (e == hipSuccess) e = hipMemcpyAsync(primId, dPrim, n * 4, hipMemcpyDeviceToHost, s->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(t, dT, n * 4, hipMemcpyDeviceToHost, s->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-  (void)hipFree(dPrim); (void)hipFree(dT);
+  if (dPrim) (void)hipFree(dPrim);
+  if (dT) (void)hipFree(dT);
   if (e != hipSuccess) return failMsg(RT_ERR_DEVICE, std::string("rt_trace_primary: ") + hipGetErrorString(e));
   return RT_OK;
 }
