@@ -161,7 +161,10 @@ class TreeBuilder {
         const float c[3] = {o.centroid.x, o.centroid.y, o.centroid.z};
         for (int a = 0; a < 3; ++a) {
           if (!use[a]) continue;
-          int k = std::min(kBins - 1, static_cast<int>((c[a] - ext.lo[a]) * toBin[a]));
+          // min(15, int(x)) for every x the reference can convert; a NaN or infinite centroid (for which that conversion
+          // is undefined and the reference indexes out of bounds) lands in the first / last bin instead
+          const float x = (c[a] - ext.lo[a]) * toBin[a];
+          const int k = x >= 0.0f ? (x < (float)kBins ? static_cast<int>(x) : kBins - 1) : 0;
           bins.box[a][k].add(o.aabbMin, o.aabbMax);
           bins.count[a][k]++;
         }

@@ -167,6 +167,28 @@ def test_host_thread_count_never_changes_the_result(scene_path):
     assert out[0] == out[1]
 
 
+def test_degenerate_mesh_builds_without_undefined_behaviour():
+    """A mesh whose vertices coincide: the OBJ scaling divides by a zero extent (src/parser/parser.cpp:94), every
+    triangle is NaN, and the reference's BVH build converts a NaN to a bin index (undefined: an out-of-bounds write on
+    x86). Here the build is defined, the objects stay in the tree and no ray hits them."""
+    hs = capi.HostScene.new(16, 16)
+    m = hs.add_material(capi.RT_MAT_DEFAULT)
+    hs.add_mesh(np.zeros((3, 3)), None, np.array([[0, 1, 2]] * 9), material=m)
+    for i in range(6):
+        hs.add_sphere((i - 2.5, 0, -4), 0.4, material=m)
+    hs.add_light(capi.RT_LIGHT_POINT, color=(5, 5, 5, 1), v=(0, 3, 0))
+    hs.set_camera(); hs.set_options(16, 16, numRays=2)
+    hs.build()
+    d = hs.desc.contents
+    assert d.numPrims == 15 and d.numNodes >= 1
+    osc = oracle_scene(hs.desc)
+    ids, t = osc.trace_primary()
+    assert (ids >= 0).any() and not np.isin(ids[ids >= 0], np.arange(9)).any()  # only the spheres (inserted after the mesh) are hit
+    img, _ = osc.render(seed=1)
+    assert np.isfinite(img).all()
+    osc.close()
+
+
 def test_empty_scene_and_planes_only(tmp_path):
     p = tmp_path / "empty.txt"; p.write_text("png 8 8 a.png\n")
     hs = capi.HostScene.load(str(p)).build()

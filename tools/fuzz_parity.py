@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""GPU box: randomised parity. Random scenes (triangle soups with degenerate and huge triangles, spheres, planes, point /
+distant / environment lights, random materials), random cameras, and rays with extreme directions (zero components,
+tiny and huge lengths, origins inside boxes and far away): closest and any-hit queries must equal the CPU restatement
+bit for bit; rendered frames must have the same alpha and at most 1 % of their pixels off by more than 1e-3.
+
+    python tools/fuzz_parity.py [--seconds 120] [--seed 1]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raytracer_amd import capi  # noqa: E402
+from tests.oracle_binding import oracle_scene  # noqa: E402
+
+
+def random_scene(rng, k):
+    w, h = int(rng.integers(8, 97)), int(rng.integers(8, 97))
+    hs = capi.HostScene.new(w, h)
+    mats = [hs.add_material(capi.RT_MAT_DEFAULT)]
+    for t in (capi.RT_MAT_GLASS, capi.RT_MAT_MIRROR, capi.RT_MAT_PLASTIC, capi.RT_MAT_METAL):
+        mats.append(hs.add_material(t, Kd=float(rng.uniform(0.2, 1)), Ks=float(rng.uniform(0, 1)), eta=float(rng.uniform(1.1, 2.5)),
+                                    Kr=float(rng.uniform(0.2, 1)), Kt=float(rng.uniform(0.2, 1)), Ka=float(rng.uniform(0.5, 4)),
+                                    roughness=float(rng.uniform(0, 0.5))))
+    ntri = int(rng.choice([0, 1, 3, 50, 700, 5000]))
+    if ntri:
+        nv = max(3, ntri // 2)
+        scale = float(rng.choice([0.05, 1.0, 30.0]))
+        v = rng.normal(size=(nv, 3)) * scale
+        if k % 3 == 0:
+            v = np.round(v * 4) / 4          # many coplanar / collinear points, exact ties in t
+        f = rng.integers(0, nv, size=(ntri, 3))
+        f[::11, 1] = f[::11, 0]              # degenerate triangles
+        hs.add_mesh(v, rng.normal(size=(nv, 3)), f, center=tuple(rng.normal(size=3) * 0.5 + np.array([0, 0, -3])),
+                    scale=float(rng.uniform(0.5, 4)), color=tuple(rng.uniform(0, 1, size=3)) + (1.0,), material=int(rng.choice(mats)))
+    for _ in range(int(rng.choice([0, 1, 5, 40]))):
+        hs.add_sphere(tuple(rng.normal(size=3) * 1.5 + np.array([0, 0, -3])), float(rng.uniform(0.05, 1.2)),
+                      color=tuple(rng.uniform(0, 1, size=3)) + (1.0,), material=int(rng.choice(mats)))
+    for _ in range(int(rng.choice([0, 1, 2]))):
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        hs.add_plane(tuple(n), float(rng.uniform(1, 4)), color=tuple(rng.uniform(0, 1, size=3)) + (1.0,), material=int(rng.choice(mats)))
+    kinds = rng.choice([capi.RT_LIGHT_POINT, capi.RT_LIGHT_DISTANT, capi.RT_LIGHT_ENVIRONMENT], size=int(rng.integers(0, 4)))
+    for t in kinds:
+        if t == capi.RT_LIGHT_POINT:  # some bulbs closer than 1 unit to the geometry (|d| < 1 visibility rays)
+            hs.add_light(t, color=tuple(rng.uniform(0, 6, size=3)) + (1.0,), v=tuple(rng.normal(size=3) * 0.7 + np.array([0, 0, -3])))
+        elif t == capi.RT_LIGHT_DISTANT:
+            hs.add_light(t, color=tuple(rng.uniform(0, 1, size=3)) + (1.0,), v=tuple(rng.normal(size=3)))
+        else:
+            hs.add_light(t, color=tuple(rng.uniform(0, 0.5, size=3)) + (1.0,), radius=float(rng.uniform(5, 20)))
+    fwd = rng.normal(size=3) * 0.2 + np.array([0, 0, -1])
+    hs.set_camera(eye=tuple(rng.normal(size=3) * 0.3), forward=tuple(fwd), up=(0, 1, 0))
+    mode = k % 4
+    hs.set_options(w, h, maxBounces=int(rng.integers(1, 6)), numRays=int(rng.integers(1, 5)),
+                   fisheye=1 if mode == 1 else 0, focus=2.5 if mode == 2 else -1.0, lens=0.2 if mode == 2 else 0.0,
+                   exposure=1.5 if mode == 3 else -1.0)
+    return hs.build()
+
+
+def random_rays(rng, n):
+    o = rng.normal(size=(n, 3)) * np.array([3, 2, 3]) + np.array([0, 0, -3])
+    o[::7] *= 40
+    d = rng.normal(size=(n, 3)) * np.exp(rng.normal(size=(n, 1)) * 3)
+    for c in range(3):
+        d[c::13, c] = 0.0
+    d[5::17] = np.round(d[5::17])          # axis-aligned and diagonal directions, zero vectors
+    return o.astype(np.float32), d.astype(np.float32)
+
+
+def same_bits(a, b):
+    """Bit-equal, except that any NaN equals any NaN: x86 and gfx950 give NaNs of different sign and payload (a
+    zero-length shading normal divided by its length, for instance)."""
+    if a.dtype.kind != "f":
+        return np.array_equal(a, b)
+    return bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))
+
+
+def detail(hs, dev, orc, o, d):
+    dsc = hs.desc.contents
+    print(f"scene: prims {dsc.numPrims} nodes {dsc.numNodes} planes {dsc.numPlanes}")
+    names = ("id", "t", "point", "normal")
+    g, r = dev.trace_closest(o, d), orc.trace_closest(o, d)
+    for nm, a, b in zip(names, g, r):
+        neq = (a.view(np.uint32) != b.view(np.uint32)) & ~((a != a) & (b != b)) if a.dtype.kind == 'f' else a != b
+        rows = np.unique(np.nonzero(neq)[0])
+        print(f"closest {nm}: {rows.size} rays differ")
+        for i in rows[:5]:
+            print(f"   ray {i}: o {o[i].tolist()} d {d[i].tolist()} gpu id {g[0][i]} t {g[1][i]!r} cpu id {r[0][i]} t {r[1][i]!r} "
+                  f"gpu {nm} {a[i].tolist() if a.ndim > 1 else a[i]} cpu {b[i].tolist() if b.ndim > 1 else b[i]}")
+    ga, ra = dev.trace_any(o, d), orc.trace_any(o, d)
+    rows = np.nonzero(ga != ra)[0]
+    print(f"any: {rows.size} rays differ")
+    for i in rows[:5]:
+        print(f"   ray {i}: o {o[i].tolist()} d {d[i].tolist()} gpu {ga[i]} cpu {ra[i]} closest gpu id {g[0][i]} t {g[1][i]!r}")
+    gi, gt = dev.trace_primary(); oi, ot = orc.trace_primary()
+    print(f"primary: {(gi != oi).sum()} ids, {(gt.view(np.uint32) != ot.view(np.uint32)).sum()} t differ")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--only", type=int, default=-1, help="replay the random stream up to this scene and report on it in detail")
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    t0 = time.time()
+    k = bad = rays = diverged = 0
+    while time.time() - t0 < args.seconds:
+        hs = random_scene(rng, k)
+        o, d = random_rays(rng, 20000)
+        if args.only >= 0 and k < args.only:
+            k += 1
+            continue
+        dev, orc = capi.device_scene(hs.desc), oracle_scene(hs.desc, threads=8)
+        if args.only >= 0:
+            detail(hs, dev, orc, o, d)
+            return 0
+        g, r = dev.trace_closest(o, d), orc.trace_closest(o, d)
+        ok = all(same_bits(a, b) for a, b in zip(g, r))
+        ok = ok and np.array_equal(dev.trace_any(o, d), orc.trace_any(o, d))
+        gi, gt = dev.trace_primary(); oi, ot = orc.trace_primary()
+        ok = ok and np.array_equal(gi, oi) and same_bits(gt, ot)
+        img, st = dev.render(seed=k); ref, ost = orc.render(seed=k)
+        finite = np.isfinite(ref).all() and np.isfinite(img).all()
+        mse = float(((img[..., :3] - ref[..., :3]) ** 2).mean()) if finite else 0.0
+        psnr = 200.0 if mse == 0 else 10 * np.log10(1.0 / mse)
+        same_counts = st.raysClosest + st.raysAny + st.raysSkipped == ost.raysClosest + ost.raysAny
+        # A last-bit difference between the device's and glibc's sinf / cosf / acosf can send ONE path of a frame the other
+        # way at a branch (lobe choice, Fresnel test): a handful of rays more or less and a few pixels off. That is
+        # counted apart ("diverged"); a mismatch is anything more: queries not bit-equal, alpha differing, or more
+        # than 1 % of the pixels off.
+        npx = img.shape[0] * img.shape[1]
+        off = int((np.abs(img[..., :3] - ref[..., :3]).max(-1) > 1e-3).sum()) if finite else npx
+        ok_img = np.array_equal(img[..., 3], ref[..., 3]) and off <= max(2, npx // 100)
+        diverged += int(ok and ok_img and not same_counts)
+        rays += 2 * len(o) + gi.size + st.raysClosest + st.raysAny
+        if not (ok and ok_img):
+            bad += 1
+            d_ = hs.desc.contents
+            o_ = d_.options
+            nbad = int((np.abs(img[..., :3] - ref[..., :3]).max(-1) > 1e-3).sum()) if finite else -1
+            print(f"MISMATCH scene {k}: prims {d_.numPrims} planes {d_.numPlanes} lights {d_.numLights} queries_ok {ok} "
+                  f"alpha_ok {np.array_equal(img[..., 3], ref[..., 3])} psnr {psnr:.1f} counts {same_counts} | {o_.width}x{o_.height} "
+                  f"spp {o_.numRays} bounces {o_.maxBounces} mode {k % 4} pixels>1e-3: {nbad} rays gpu "
+                  f"{st.raysClosest + st.raysAny + st.raysSkipped} cpu {ost.raysClosest + ost.raysAny}", flush=True)
+        dev.close(); orc.close()
+        k += 1
+        if k % 500 == 0:
+            print(f"{k} scenes, {rays / 1e6:.1f} M rays, {bad} mismatches, {diverged} frames with a diverged path, {time.time() - t0:.0f} s", flush=True)
+    print(f"done: {k} scenes, {rays / 1e6:.1f} M rays, {bad} mismatches, {diverged} frames with a diverged path")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
