@@ -25,6 +25,16 @@ def random_scene(rng, k):
         mats.append(hs.add_material(t, Kd=float(rng.uniform(0.2, 1)), Ks=float(rng.uniform(0, 1)), eta=float(rng.uniform(1.1, 2.5)),
                                     Kr=float(rng.uniform(0.2, 1)), Kt=float(rng.uniform(0.2, 1)), Ka=float(rng.uniform(0.5, 4)),
                                     roughness=float(rng.uniform(0, 0.5))))
+    # smooth textures (a last-bit difference in the texture coordinate then moves the colour by little) on some scenes
+    texs = []
+    if k % 5 == 0:
+        for _ in range(2):
+            th, tw = int(rng.integers(2, 40)), int(rng.integers(2, 40))
+            yy, xx = np.mgrid[0:th, 0:tw]
+            img = np.stack([0.5 + 0.4 * np.sin(xx / tw * 6 + rng.uniform(0, 6)), 0.5 + 0.4 * np.cos(yy / th * 5), 0.3 + 0.2 * np.sin((xx + yy) / 9.0),
+                            np.ones_like(xx, dtype=float)], -1)
+            texs.append(hs.add_texture(img))
+    pick_tex = lambda: int(rng.choice(texs)) if texs and rng.random() < 0.6 else -1
     ntri = int(rng.choice([0, 1, 3, 50, 700, 5000]))
     if ntri:
         nv = max(3, ntri // 2)
@@ -38,10 +48,12 @@ def random_scene(rng, k):
                     scale=float(rng.uniform(0.5, 4)), color=tuple(rng.uniform(0, 1, size=3)) + (1.0,), material=int(rng.choice(mats)))
     for _ in range(int(rng.choice([0, 1, 5, 40]))):
         hs.add_sphere(tuple(rng.normal(size=3) * 1.5 + np.array([0, 0, -3])), float(rng.uniform(0.05, 1.2)),
-                      color=tuple(rng.uniform(0, 1, size=3)) + (1.0,), material=int(rng.choice(mats)))
+                      color=tuple(rng.uniform(0, 1, size=3)) + (1.0,), material=int(rng.choice(mats)), texture=pick_tex())
     for _ in range(int(rng.choice([0, 1, 2]))):
         n = rng.normal(size=3); n /= np.linalg.norm(n)
-        hs.add_plane(tuple(n), float(rng.uniform(1, 4)), color=tuple(rng.uniform(0, 1, size=3)) + (1.0,), material=int(rng.choice(mats)))
+        hs.add_plane(tuple(n), float(rng.uniform(1, 4)), color=tuple(rng.uniform(0, 1, size=3)) + (1.0,), material=int(rng.choice(mats)),
+                     tex_top_left=tuple(rng.normal(size=3)), tex_zoom=float(rng.uniform(1, 30)), tex_shift=tuple(rng.normal(size=3)),
+                     texture=pick_tex())
     kinds = rng.choice([capi.RT_LIGHT_POINT, capi.RT_LIGHT_DISTANT, capi.RT_LIGHT_ENVIRONMENT], size=int(rng.integers(0, 4)))
     for t in kinds:
         if t == capi.RT_LIGHT_POINT:  # some bulbs closer than 1 unit to the geometry (|d| < 1 visibility rays)
@@ -49,7 +61,7 @@ def random_scene(rng, k):
         elif t == capi.RT_LIGHT_DISTANT:
             hs.add_light(t, color=tuple(rng.uniform(0, 1, size=3)) + (1.0,), v=tuple(rng.normal(size=3)))
         else:
-            hs.add_light(t, color=tuple(rng.uniform(0, 0.5, size=3)) + (1.0,), radius=float(rng.uniform(5, 20)))
+            hs.add_light(t, color=tuple(rng.uniform(0, 0.5, size=3)) + (1.0,), radius=float(rng.uniform(5, 20)), texture=pick_tex())
     fwd = rng.normal(size=3) * 0.2 + np.array([0, 0, -1])
     hs.set_camera(eye=tuple(rng.normal(size=3) * 0.3), forward=tuple(fwd), up=(0, 1, 0))
     mode = k % 4
