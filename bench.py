@@ -201,7 +201,7 @@ def main():
     line = {
         "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
-        "scaling": "strong",  # the frame (total work) is fixed as GPUs are added "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",  # strong: one fixed frame for every N
         "config": {"workload": f"README-scene stand-in: {W}x{H}, {o.numRays} spp, {tris} BVH objects + {d.numPlanes} planes, "
                                f"point + environment light, maxBounces {o.maxBounces}",
                    "width": W, "height": H, "spp": o.numRays, "objects": tris, "bvh_nodes": int(d.numNodes),
