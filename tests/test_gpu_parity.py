@@ -47,7 +47,7 @@ def test_primary_hits_bit_exact_vs_reference_fixture(name, scenes, golden):
 
 
 def test_primary_hits_config2_full_size(scenes, golden):
-    """BASELINE config 2: 1080x1080 primary rays on the ~70k-triangle mesh; every id and t bit pattern."""
+    """The primary-rays-only configuration: 1080x1080 primary rays on the ~70k-triangle mesh; every id and t bit pattern."""
     g = golden("mesh70k")
     _, dev, orc = scenes("mesh70k")
     ids, t = dev.trace_primary()
@@ -92,7 +92,7 @@ def test_full_size_benchmark_scene(scenes, golden):
 
 
 def test_config5_shape_4k_multi_million_triangles():
-    """BASELINE config 5 in shape (3840x2160, in-memory procedural mesh, GI with point + environment light), at 2 M
+    """The 10 M-triangle stress configuration in shape (3840x2160, in-memory procedural mesh, GI with point + environment light), at 2 M
     triangles so that the host build stays short; tools/config5_stress.py runs the 10 M-triangle size."""
     from tools import config5_stress
     hs, tris = config5_stress.build_scene(1000, 3840, 2160, 1, 4)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU box: BASELINE config 2 (1080x1080 primary rays on the ~70 k-triangle mesh): rt_trace_primary and the 1-spp render."""
+"""GPU box: the primary-rays-only configuration (1080x1080 primary rays on the ~70 k-triangle mesh): rt_trace_primary and the 1-spp render."""
 import os
 import sys
 import tempfile

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""BASELINE config 5 on one GPU: a procedural ~10 M-triangle mesh (built in memory through the host C API, no OBJ text),
+"""The 10 M-triangle stress configuration on one GPU: a procedural ~10 M-triangle mesh (built in memory through the host C API, no OBJ text),
 3840x2160, multi-bounce GI with a point and an environment light.
 
     python tools/config5_stress.py [--tris-side 2237] [--width 3840 --height 2160] [--spp 4] [--check-pixels 200000]
