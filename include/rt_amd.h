@@ -202,12 +202,23 @@ int rt_render(RtScene *scene, const RtRenderParams *params, float *rgbaOut, RtSt
 /* Device pointer of the float RGBA framebuffer of the last rt_render on this scene (width*height*4 floats). */
 const float *rt_framebuffer_device(RtScene *scene);
 
+/* Multi-GPU gather: adds the framebuffer of `src` (last rt_render there) to the framebuffer of `dst`, on dst's device;
+ * the copy is device to device (xGMI between GPUs of a node). Meant for scenes that rendered disjoint tile partitions
+ * of the same image: pixels outside a partition are exactly 0, so the sum is the gathered frame, bit for bit. This is
+ * the join of the reference's worker threads (src/scene/raytracer.cpp:276-279), which write into one shared image. */
+int rt_framebuffer_add(RtScene *dst, RtScene *src);
+
+/* Copies the float RGBA framebuffer of the last rt_render (after any rt_framebuffer_add) to rgbaOut
+ * (width*height*4 floats, host or device memory). */
+int rt_framebuffer_read(RtScene *scene, float *rgbaOut);
+
 /* PNG::saveToFile's pixel conversion (src/image/PNG.cpp:149-157): sRGB transfer + round(c*255), on the
  * device, from the framebuffer of the last rt_render; rgba8Out: width*height*4 bytes (host). */
 int rt_resolve_rgba8(RtScene *scene, uint8_t *rgba8Out);
 
 const char *rt_last_error(void);
 const char *rt_version(void);
+int rt_device_count(void); /* GPUs this process can use (0 when there is none) */
 
 #ifdef __cplusplus
 }

@@ -972,6 +972,21 @@ int rto_render(RtoScene *s, const RtRenderParams *params, float *rgbaOut, RtStat
 
 const float *rto_framebuffer_device(RtoScene *s) { return s ? s->framebuffer.data() : nullptr; }
 
+int rto_device_count(void) { return 0; }  // the CPU restatement uses no GPU
+
+int rto_framebuffer_add(RtoScene *dst, RtoScene *src) {  // host mirror of rt_framebuffer_add
+  if (!dst || !src || dst == src) return fail("rto_framebuffer_add needs two different scenes");
+  if (dst->framebuffer.size() != src->framebuffer.size() || dst->framebuffer.empty()) return fail("framebuffers differ in size");
+  for (size_t i = 0; i < dst->framebuffer.size(); ++i) dst->framebuffer[i] = dst->framebuffer[i] + src->framebuffer[i];
+  return RT_OK;
+}
+
+int rto_framebuffer_read(RtoScene *s, float *out) {
+  if (!s || !out) return fail("null argument");
+  std::copy(s->framebuffer.begin(), s->framebuffer.end(), out);
+  return RT_OK;
+}
+
 int rto_resolve_rgba8(RtoScene *s, uint8_t *out) {  // PNG::saveToFile, src/image/PNG.cpp:149-157
   if (!s || !out) return fail("null argument");
   for (size_t i = 0; i < s->framebuffer.size() / 4; ++i) {

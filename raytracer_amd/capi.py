@@ -324,6 +324,9 @@ def bind_render_abi(L, prefix):
     fn("render").argtypes = [vp, C.POINTER(RtRenderParams), f32p, C.POINTER(RtStats)]
     fn("framebuffer_device").restype = vp; fn("framebuffer_device").argtypes = [vp]
     fn("resolve_rgba8").argtypes = [vp, C.POINTER(C.c_uint8)]
+    fn("framebuffer_add").argtypes = [vp, vp]
+    fn("framebuffer_read").argtypes = [vp, f32p]
+    fn("device_count").restype = C.c_int
     fn("last_error").restype = C.c_char_p
     fn("version").restype = C.c_char_p
     return L
@@ -406,6 +409,15 @@ class RenderScene:
 
     def framebuffer_device(self):
         return self._f("framebuffer_device")(self._h)
+
+    def framebuffer_add(self, other):
+        """Adds `other`'s last frame to this scene's (device to device): the gather of disjoint tile partitions."""
+        self._check(self._f("framebuffer_add")(self._h, other._h), "framebuffer_add")
+
+    def framebuffer_read(self):
+        out = np.empty((self.height, self.width, 4), dtype=np.float32)
+        self._check(self._f("framebuffer_read")(self._h, _fp(out)), "framebuffer_read")
+        return out
 
     def resolve_rgba8(self):
         out = np.empty((self.height, self.width, 4), dtype=np.uint8)

@@ -458,6 +458,14 @@ RT_DEV float linearToGamma(float channel) {
   if ((double)channel < 0.0031308) return (float)(12.92 * (double)channel);
   return (float)(1.055 * pow((double)channel, 1 / 2.4) - 0.055);
 }
+// dst += src, component by component: tile partitions own disjoint pixels and leave the others exactly 0
+__global__ __launch_bounds__(kBlock) void k_add_frame(float4 *dst, const float4 *src, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  float4 a = dst[i], b = src[i];
+  dst[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
 __global__ __launch_bounds__(kBlock) void k_srgb8(const float4 *fb, uchar4 *out, int32_t n) {
   int32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
@@ -982,6 +990,10 @@ inline unsigned persistentGrid(const RtScene *s, int64_t n) {
 extern "C" {
 
 const char *rt_last_error(void) { return g_error.c_str(); }
+int rt_device_count(void) {
+  int count = 0;
+  return hipGetDeviceCount(&count) == hipSuccess ? count : 0;
+}
 const char *rt_version(void) { return "raytracer_amd 0.1 (gfx950 wavefront path tracer)"; }
 
 RtScene *rt_scene_create(const RtSceneDesc *desc, int device) {
@@ -1264,6 +1276,38 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
 }
 
 const float *rt_framebuffer_device(RtScene *s) { return s ? reinterpret_cast<const float *>(s->fb) : nullptr; }
+
+int rt_framebuffer_add(RtScene *dst, RtScene *src) {
+  if (!dst || !src || dst == src) return failMsg(RT_ERR_INVALID, "rt_framebuffer_add needs two different scenes");
+  if (!dst->fb || !src->fb) return failMsg(RT_ERR_INVALID, "rt_render has not run on both scenes");
+  int64_t n = (int64_t)dst->dev.width * dst->dev.height;
+  if (n != (int64_t)src->dev.width * src->dev.height || n > dst->fbPixels || n > src->fbPixels)
+    return failMsg(RT_ERR_INVALID, "the two framebuffers have different sizes");
+  HIP_TRY(hipSetDevice(dst->device));
+  float4 *staging = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&staging), n * sizeof(float4));
+  // device-to-device: over xGMI when the scenes live on different GPUs of a node (rt_render has synchronised src's stream)
+  if (e == hipSuccess) e = hipMemcpyPeerAsync(staging, dst->device, src->fb, src->device, n * sizeof(float4), dst->stream);
+  if (e == hipSuccess) {
+    k_add_frame<<<gridFor(n), kBlock, 0, dst->stream>>>(dst->fb, staging, n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(dst->stream);
+  if (staging) (void)hipFree(staging);
+  if (e != hipSuccess) return failMsg(RT_ERR_DEVICE, std::string("rt_framebuffer_add: ") + hipGetErrorString(e));
+  return RT_OK;
+}
+
+int rt_framebuffer_read(RtScene *s, float *rgbaOut) {
+  if (!s || !rgbaOut) return failMsg(RT_ERR_INVALID, "null argument");
+  if (!s->fb) return failMsg(RT_ERR_INVALID, "rt_render has not run on this scene");
+  HIP_TRY(hipSetDevice(s->device));
+  int64_t n = (int64_t)s->dev.width * s->dev.height;
+  if (n > s->fbPixels) return failMsg(RT_ERR_INVALID, "framebuffer is smaller than the current image size");
+  HIP_TRY(hipMemcpyAsync(rgbaOut, s->fb, n * sizeof(float4), hipMemcpyDefault, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RT_OK;
+}
 
 int rt_resolve_rgba8(RtScene *s, uint8_t *rgba8Out) {
   if (!s || !rgba8Out) return failMsg(RT_ERR_INVALID, "null argument");

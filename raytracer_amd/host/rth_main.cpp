@@ -6,6 +6,8 @@
 // the output file named by the scene, exit codes 1 (usage / unreadable scene) and -1 (unknown flag).
 // Added (none of them changes `./raytracer [-tN] file`):
 //   --gpus N        split the frame by interleaved image tiles over N devices of this node, gather on device 0
+//   --share-gpus    with --gpus N on a node with fewer than N devices: several parts per device (a rehearsal of the
+//                   N-way split and gather, not a speed-up)
 //   --tile WxH      tile size of that split (default 32x32)
 //   --spp-pass N    camera samples per pixel traced per wavefront pass
 //   --seed N        seed of the counter-based random stream (default 56, the reference's unused `seed` default)
@@ -51,7 +53,7 @@ int main(int argc, char **argv) {
   int numThreads = 0;  // 0 = not given: the host library picks (the reference's default of 4 is a CPU-render setting)
   int gpus = 1, tileW = 32, tileH = 32, sppPass = 0;
   unsigned seed = 56;
-  bool stats = false;
+  bool stats = false, shareGpus = false;
   std::string dumpHits, path;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -67,6 +69,7 @@ int main(int argc, char **argv) {
     else if (a == "--seed") seed = (unsigned)std::strtoul(next("--seed"), nullptr, 10);
     else if (a == "--dump-hits") dumpHits = next("--dump-hits");
     else if (a == "--stats") stats = true;
+    else if (a == "--share-gpus") shareGpus = true;
     else if (!a.empty() && a[0] == '-') return usage(argv[0], -1);
     else path = a;
   }
@@ -102,8 +105,13 @@ int main(int argc, char **argv) {
 
   const int W = desc->options.width, H = desc->options.height;
   std::vector<RtScene *> scenes(gpus, nullptr);
+  const int devices = rt_device_count();
+  if (gpus > devices && !(shareGpus && devices > 0)) {
+    std::fprintf(stderr, "--gpus %d, but this node offers %d device(s)\n", gpus, devices);
+    return 1;
+  }
   for (int g = 0; g < gpus; ++g) {
-    scenes[g] = rt_scene_create(desc, g);
+    scenes[g] = rt_scene_create(desc, g % devices);
     if (!scenes[g]) {
       std::fprintf(stderr, "device %d: %s\n", g, rt_last_error());
       return 1;
@@ -135,22 +143,29 @@ int main(int argc, char **argv) {
     rc[0] = rt_render(scenes[0], &p, frame.data(), &st[0]);
     if (rc[0] != RT_OK) errs[0] = rt_last_error();
   } else {
-    // One host thread per device; every device renders its interleaved tiles of the frame. Pixels outside a device's
-    // tiles come back as 0, so the frames combine by addition (x + 0 is exact).
-    std::vector<std::vector<float>> parts(gpus, std::vector<float>((size_t)W * H * 4));
+    // One host thread per device; every device renders its interleaved tiles of the frame and keeps them in its own
+    // memory. Device 0 then collects the partial frames device to device (pixels outside a device's tiles are 0, so
+    // adding is exact) and the host reads the finished frame once.
     std::vector<std::thread> workers;
     for (int g = 0; g < gpus; ++g) {
       workers.emplace_back([&, g]() {
         RtRenderParams p{};
         p.rngMode = RT_RNG_COUNTER; p.seed = seed; p.partIndex = g; p.partCount = gpus; p.tileW = tileW; p.tileH = tileH;
         p.samplesPerPass = sppPass;
-        rc[g] = rt_render(scenes[g], &p, parts[g].data(), &st[g]);
+        rc[g] = rt_render(scenes[g], &p, nullptr, &st[g]);
         if (rc[g] != RT_OK) errs[g] = rt_last_error();
       });
     }
     for (auto &w : workers) w.join();
-    for (int g = 0; g < gpus; ++g)
-      for (size_t i = 0; i < frame.size(); ++i) frame[i] += parts[g][i];
+    for (int g = 1; g < gpus && rc[0] == RT_OK; ++g) {
+      if (rc[g] != RT_OK) continue;
+      rc[g] = rt_framebuffer_add(scenes[0], scenes[g]);
+      if (rc[g] != RT_OK) errs[g] = rt_last_error();
+    }
+    if (rc[0] == RT_OK) {
+      rc[0] = rt_framebuffer_read(scenes[0], frame.data());
+      if (rc[0] != RT_OK) errs[0] = rt_last_error();
+    }
   }
   for (int g = 0; g < gpus; ++g)
     if (rc[g] != RT_OK) {

@@ -49,6 +49,13 @@ def test_cli_renders_the_scene_file(scene_path, tmp_path):
     # the device-side conversion (rt_resolve_rgba8) agrees with the host's
     assert np.array_equal(dev.resolve_rgba8().reshape(h, w, 4), want)
     dev.close()
+    # --gpus 3 on this one GPU (--share-gpus): three tile partitions, device-to-device gather, the same PNG
+    os.rename(out_png, out_png + ".one")
+    r = run("--gpus", "3", "--share-gpus", "--tile", "16x8", src, cwd=os.path.dirname(src))
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(capi.png_read_rgba8(out_png), capi.png_read_rgba8(out_png + ".one"))
+    r = run("--gpus", "64", src, cwd=os.path.dirname(src))
+    assert r.returncode == 1 and "device" in r.stderr
     # --dump-hits: ids and t of the primary rays, same as rt_trace_primary
     dump = str(tmp_path / "hits.bin")
     r = run("--dump-hits", dump, src, cwd=os.path.dirname(src))

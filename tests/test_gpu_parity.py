@@ -196,6 +196,27 @@ def test_samples_per_pass_does_not_change_the_image(scenes):
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(a.view(np.uint32), c.view(np.uint32))
 
 
+def test_device_to_device_gather_of_tile_partitions(scenes):
+    """rt_framebuffer_add: three scene handles render the three tile partitions of one frame and keep them on the
+    device; gathered on the first handle they are the whole frame, bit for bit (the path the command line takes with
+    --gpus N; on one GPU the peer copy is a plain device copy)."""
+    hs, dev, _ = scenes("readme_small")
+    whole, _ = dev.render(seed=9)
+    parts = [capi.device_scene(hs.desc) for _ in range(3)]
+    try:
+        for r, p in enumerate(parts):
+            p.render(seed=9, part_index=r, part_count=3, tile=(16, 16), download=False)
+        parts[0].framebuffer_add(parts[1])
+        parts[0].framebuffer_add(parts[2])
+        got = parts[0].framebuffer_read()
+        assert np.array_equal(got.reshape(whole.shape).view(np.uint32), whole.view(np.uint32))
+        with pytest.raises(RuntimeError, match="two different scenes"):
+            parts[0].framebuffer_add(parts[0])
+    finally:
+        for p in parts:
+            p.close()
+
+
 def test_counters_match_oracle_work(scenes):
     """With collectCounters the kernels count inner-node expansions and primitive tests. For path-extension queries
     the visit rule is the reference's, so on RNG-free scenes the counts equal the CPU loop's exactly; point-light
