@@ -99,8 +99,89 @@ def random_txt(rng, tmp, k):
     return path
 
 
+def vec(rng, lo=-4.0, hi=4.0, zlo=None, zhi=None):
+    z = num(rng, lo, hi) if zlo is None else num(rng, zlo, zhi)
+    sp = lambda: " " * int(rng.integers(0, 3))
+    return f"({sp()}{num(rng, lo, hi)},{sp()}{num(rng, lo, hi)},{sp()}{z}{sp()})"
+
+
+def random_sdml(rng, tmp, k):
+    """A random .sdml scene: every tag and option the loader knows, in random order (lights anywhere: they are read
+    last), named and ad-hoc materials, textures, OBJ includes, optional options left out at random."""
+    w, h = int(rng.integers(4, 40)), int(rng.integers(4, 40))
+    opts = [f"width: {w}", f"height: {h}", f"filename: out_{k}.png"]
+    if rng.random() < 0.7: opts.append(f"numRays: {int(rng.integers(1, 5))}")
+    if rng.random() < 0.7: opts.append(f"maxBounces: {int(rng.integers(1, 7))}")
+    if rng.random() < 0.4: opts.append(f"bias: {num(rng, 1e-5, 1e-3)}")
+    if rng.random() < 0.3: opts.append(f"exposure: {num(rng, 0.5, 4)}")
+    mode = rng.integers(0, 4)
+    if mode == 1: opts.append("fisheye: 1")
+    if mode == 2: opts += [f"focus: {num(rng, 1, 5)}", f"lens: {int(rng.integers(0, 3))}"]
+    rng.shuffle(opts)
+    body = []
+    if rng.random() < 0.8:
+        cam = []
+        if rng.random() < 0.7: cam.append("eye: " + vec(rng, -1, 1))
+        if rng.random() < 0.7: cam.append("forward: " + vec(rng, -0.4, 0.4, -2, -0.5))
+        if rng.random() < 0.5: cam.append("up: " + vec(rng, -1, 1))
+        body.append("  <Camera options={%s}/>" % "; ".join(cam))
+    names = ["glass", "plastic", "mirror", "copper penny", "metallic gold", "something else"]
+
+    def inner():
+        out = []
+        r = rng.random()
+        if r < 0.45:
+            out.append(f'    <Material name="{rng.choice(names)}"/>')
+        elif r < 0.65:
+            t = str(rng.choice(["glass", "mirror", "plastic", "metal", "dialectric"]))
+            fields = [f"type: {t}"]
+            for key, lo, hi in (("Kd", 0, 1), ("Ks", 0, 1), ("eta", 1.1, 2.5), ("Kr", 0.1, 1), ("Kt", 0.1, 1), ("Ka", 0.5, 4), ("roughness", 0, 0.5)):
+                if t != "dialectric" or rng.random() < 0.5:
+                    fields.append(f"{key}: {num(rng, lo, hi)}")
+            if t != "dialectric":
+                out.append("    <Material options={%s}/>" % "; ".join(fields))
+        if rng.random() < 0.3:
+            out.append(f'    <Texture path="{os.path.join(tmp, str(rng.choice(["marble.png", "wood.png"])))}"/>')
+        return out
+
+    for _ in range(int(rng.integers(1, 25))):
+        kind = rng.choice(["sphere", "triangle", "plane", "point", "distant", "environment", "wavefront"], p=[.3, .25, .1, .1, .08, .07, .1])
+        col = ("; color: " + vec(rng, 0, 1.2)) if rng.random() < 0.6 else ""
+        if kind == "sphere":
+            o = [f"radius: {num(rng, 0.05, 1.2)}", "center: " + vec(rng, -3, 3, -6, -1)]
+            rng.shuffle(o)
+            body += ['  <Shape type="sphere" options={%s%s}>' % ("; ".join(o), col)] + inner() + ["  </Shape>"]
+        elif kind == "triangle":
+            o = [f"p{i}: " + vec(rng, -3, 3, -6, -1) for i in (1, 2, 3)]
+            if rng.random() < 0.3: o += [f"t{i}: " + vec(rng, 0, 15) for i in (1, 2, 3)]
+            body += ['  <Shape type="triangle" options={%s%s}>' % ("; ".join(o), col)] + inner() + ["  </Shape>"]
+        elif kind == "plane":
+            o = ["normal: " + vec(rng, -1, 1), f"D: {num(rng, 0.5, 5)}"]
+            if rng.random() < 0.5: o.append(f"texture-zoom: {num(rng, 1, 50)}")
+            if rng.random() < 0.4: o.append("texture-shift: " + vec(rng, -5, 5))
+            if rng.random() < 0.3: o.append("top-left: " + vec(rng, -2, 2))
+            body += ['  <Shape type="plane" options={%s%s}>' % ("; ".join(o), col)] + inner() + ["  </Shape>"]
+        elif kind == "point":
+            body.append('  <Light type="point" options={center: %s%s}/>' % (vec(rng, -3, 3), col))
+        elif kind == "distant":
+            body.append('  <Light type="distant" options={direction: %s%s}/>' % (vec(rng, -1, 1), col))
+        elif kind == "environment":
+            if rng.random() < 0.5:
+                body.append('  <Light type="environment" options={radius: %s%s}/>' % (num(rng, 5, 20), col))
+            else:
+                body.append('  <Light type="environment" path="%s" options={radius: %s; scale: %s}/>' % (os.path.join(tmp, "sky.png"), num(rng, 5, 20), num(rng, 0.5, 2)))
+        else:
+            o = ["center: " + vec(rng, -1, 1, -5, -2), f"scale: {num(rng, 0.5, 3)}"]
+            body += ['  <Wavefront path="%s" options={%s%s}>' % (os.path.join(tmp, str(rng.choice(["blob.obj", "quirks.obj"]))), "; ".join(o), col)]
+            body += [l for l in inner() if "Texture" not in l] + ["  </Wavefront>"]
+    path = os.path.join(tmp, f"fuzz_{k}.sdml")
+    open(path, "w").write("<Scene options={%s}>\n" % "; ".join(opts) + "\n".join(body) + "\n</Scene>\n")
+    return path
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--format", choices=["txt", "sdml"], default="txt")
     ap.add_argument("--count", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--render", action="store_true",
@@ -117,7 +198,7 @@ def main():
         gen_scenes.write_obj(os.path.join(tmp, "blob.obj"), *gen_scenes.blob_mesh(9, 7))
         gen_scenes.scene_obj_quirks(tmp, "quirks")
         for k in range(args.count):
-            path = random_txt(rng, tmp, k)
+            path = random_txt(rng, tmp, k) if args.format == 'txt' else random_sdml(rng, tmp, k)
             buf = io.StringIO()
             try:
                 with redirect_stdout(buf):
@@ -131,7 +212,7 @@ def main():
                 bad += 1
                 print(buf.getvalue().strip()[:600])
                 print("   file:", path)
-    print(f"{args.count} random .txt scenes, {bad} differ from the compiled reference")
+    print(f"{args.count} random .{args.format} scenes, {bad} differ from the compiled reference")
     return 1 if bad else 0
 
 
