@@ -64,6 +64,34 @@ def test_two_ranks_equal_one(tmp_path, scene_path, scene_name, tile):
     assert np.array_equal(got["frame"], ref), "the gathered two-rank frame must equal the one-rank frame bit for bit"
 
 
+def _gather_worker(rank, world, port, width, height, tile, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # every rank holds "its" pixels of a known frame and zeros elsewhere, as rt_render leaves them
+        frame = torch.arange(height * width * 4, dtype=torch.float32).reshape(height, width, 4) + 1.0
+        own = torch.from_numpy(multi_gpu.tile_owner(width, height, tile, world) == rank)
+        out = torch.where(own[..., None], frame, torch.zeros_like(frame))
+        g = multi_gpu.TileGather(width, height, tile, rank, world, out.device)
+        for _ in range(2):  # the gatherer keeps its buffers across frames
+            g.gather(out)
+        if rank == 0:
+            np.save(result_path, out.numpy())
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,width,height,tile", [(3, 70, 50, (32, 32)), (4, 33, 17, (8, 4)), (2, 5, 3, (32, 32))])
+def test_tile_gather_ragged_sizes(tmp_path, world, width, height, tile):
+    """Tiles that do not divide the image, more ranks than tiles, three and four ranks: rank 0 ends up with every pixel."""
+    result = str(tmp_path / "frame.npy")
+    mp.spawn(_gather_worker, args=(world, _free_port(), width, height, tile, result), nprocs=world, join=True)
+    want = np.arange(height * width * 4, dtype=np.float32).reshape(height, width, 4) + 1.0
+    assert np.array_equal(np.load(result), want)
+
+
 def test_tile_owner_matches_library_rule():
     own = multi_gpu.tile_owner(70, 50, (32, 32), 3)
     assert own.shape == (50, 70)
