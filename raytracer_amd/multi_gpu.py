@@ -61,6 +61,10 @@ class TileGather:
             for r in range(1, self.world):
                 idx = self.index[r]
                 flat[idx] = self.inbox[r][: idx.numel()]
+        if out.is_cuda:
+            # the renderer writes `out` from a stream of its own: the frame must be complete before the next one starts
+            import torch
+            torch.cuda.current_stream(out.device).synchronize()
         return out
 
 
