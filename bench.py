@@ -98,6 +98,7 @@ def main():
     dev = capi.device_scene(desc, device=gpu)
     W, H = d.options.width, d.options.height
     out = torch.zeros((H, W, 4), dtype=torch.float32, device=tdev)
+    torch.cuda.synchronize()  # the library writes `out` from its own stream
     setup_s = time.time() - t_setup
 
     gatherer = multi_gpu.TileGather(W, H, (args.tile, args.tile), rank, world, out.device)
