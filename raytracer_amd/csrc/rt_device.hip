@@ -1158,10 +1158,11 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
   }
   const bool sppPassChosenHere = params->samplesPerPass <= 0;
   sppPass = std::min(sppPass, S.numRays);
-  if (sppPassChosenHere)  // path slots are 31-bit indices
-    sppPass = (int)std::max<int64_t>(1, std::min<int64_t>(sppPass, (((int64_t)1 << 31) - 1) / std::max<int64_t>(1, npix)));
+  // path slots are 31-bit indices, and the visibility queue (one entry per hit and light) is indexed with 32 bits
+  const int64_t maxPaths = std::min<int64_t>(((int64_t)1 << 31) - 1, (((int64_t)1 << 32) - ((int64_t)1 << 24)) / std::max(1, S.numLights));
+  if (sppPassChosenHere) sppPass = (int)std::max<int64_t>(1, std::min<int64_t>(sppPass, maxPaths / std::max<int64_t>(1, npix)));
   int64_t P = std::max<int64_t>(1, npix * sppPass);
-  if (P >= ((int64_t)1 << 31)) return failMsg(RT_ERR_INVALID, "samplesPerPass too large for this image");
+  if (P > maxPaths) return failMsg(RT_ERR_INVALID, "samplesPerPass too large for this image and light count");
   int rc = ensureRenderBuffers(s, P, std::max<int64_t>(1, npix), fbPixels);
   // Somebody else may have taken the memory between the query and the allocation: with a pass size chosen here, fall
   // back to smaller passes instead of failing the frame.
