@@ -102,11 +102,8 @@ constexpr uint32_t kTicketChunkMax = RT_CHUNK_MAX, kTicketChunkMin = 64, kChunks
 enum { TRAV_CLOSEST = 0, TRAV_ANY = 1, TRAV_POINT_LIGHT = 2, TRAV_SKIP = 3 };
 
 // Scheduling thresholds of the traversal engine (lanes of one 64-lane wavefront).
-#ifndef RT_REFILL_MIN
-#define RT_REFILL_MIN 16
-#endif
-#ifndef RT_FINISH_MIN
-#define RT_FINISH_MIN 16
+#ifndef RT_SERVICE_MIN
+#define RT_SERVICE_MIN 24
 #endif
 #ifndef RT_STAY_INNER
 #define RT_STAY_INNER 3
@@ -114,8 +111,7 @@ enum { TRAV_CLOSEST = 0, TRAV_ANY = 1, TRAV_POINT_LIGHT = 2, TRAV_SKIP = 3 };
 #ifndef RT_STAY_PRIM
 #define RT_STAY_PRIM 1
 #endif
-constexpr int kRefillMin = RT_REFILL_MIN;  // idle lanes before the wavefront goes back to the queue
-constexpr int kFinishMin = RT_FINISH_MIN;   // finished queries waiting before their results are written out
+constexpr int kServiceMin = RT_SERVICE_MIN;  // lanes without work (finished or idle) before results are written and the queue is visited
 
 // Limits the host checks before a scene reaches the GPU (rt_scene_create): node and object records are addressed
 // with 32-bit byte offsets, and the per-lane stack has the reference's 64 entries (src/acceleration/BVH.cpp:10), which
@@ -130,9 +126,10 @@ constexpr int kMaxTreeDepth = kMaxStack;
 //     PRIM    test one object of the current leaf
 //     FINISH  planes + result write-out of a query whose BVH part is over
 //     IDLE    no query
-// The wavefront votes: results are written once kFinishMin lanes wait for it, the queue is visited once kRefillMin
-// lanes are idle, otherwise the more popular of INNER / PRIM runs in a tight loop of its own until too few of its lanes
-// are left, while the minority waits until it has become the majority. Incoherent
+// The wavefront votes: once kServiceMin lanes have no work (their query is finished, or they never had one) a service
+// step writes the finished results out and gives every such lane a new query from the queue; otherwise the more
+// popular of INNER / PRIM runs in a tight loop of its own until too few of its lanes are left, while the minority
+// waits until it has become the majority. Incoherent
 // rays therefore do not serialise the wavefront through both loop bodies every iteration, and a few long traversals
 // do not leave most lanes waiting: finished queries are REPLACED by new ones. Per query, nodes and objects are still
 // visited in exactly the reference's order. The grid is sized to fill the GPU once (persistent wavefronts); a wavefront ends when the
@@ -211,10 +208,13 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
     const unsigned long long mInner = __ballot(op == OP_INNER), mPrim = __ballot(op == OP_PRIM);
     const int nInner = __popcll(mInner), nPrim = __popcll(mPrim);
     const int nOther = 64 - nInner - nPrim;  // finished + idle lanes
-    if (nOther >= kFinishMin || nInner + nPrim == 0) {
+    if (nOther >= kServiceMin || nInner + nPrim == 0) {
       const unsigned long long mFinish = __ballot(op >= OP_FINISH);
       const int nFinish = __popcll(mFinish), nIdle = nOther - nFinish;
-      if (nFinish > 0 && (nFinish >= kFinishMin || nInner + nPrim == 0)) {
+      // one special step serves both: finished queries are written out and, in the same step, every idle lane
+      // (the ones just finished included) takes a new query
+      const bool doFinish = nFinish > 0, doRefill = !exhausted && nIdle + nFinish > 0;
+      if (doFinish) {
         // -------------------------------------------------------------- FINISH: planes, result, lane becomes idle
         if (op >= OP_FINISH) {
           bool occluded = op == OP_FINISH_EARLY;
@@ -248,16 +248,14 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
           op = OP_IDLE;
           finite = true;
         }
-        waveExact = __ballot(!finite) != 0ull;
-        continue;
       }
-      if (!exhausted && nIdle >= kRefillMin) {
+      if (doRefill) {
         // -------------------------------------------------------------- REFILL idle lanes from the queue
         const unsigned long long mIdle = __ballot(op == OP_IDLE);
         int leader = __ffsll((long long)mIdle) - 1;
         // Queue indices come from a wave-local chunk [chunkPos, chunkEnd); one atomic on the shared counter buys
         // kTicketChunk of them, so the counter (a single address all wavefronts hit) sees few operations.
-        const uint32_t avail = chunkEnd - chunkPos, want = (uint32_t)nIdle;
+        const uint32_t avail = chunkEnd - chunkPos, want = (uint32_t)__popcll(mIdle);
         const uint32_t rank = (uint32_t)__popcll(mIdle & ((1ull << laneId) - 1ull));
         uint32_t idx = chunkPos + rank;
         if (avail < want) {
@@ -296,6 +294,7 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
         waveExact = __ballot(!finite) != 0ull;
         continue;
       }
+      if (doFinish) { waveExact = __ballot(!finite) != 0ull; continue; }
       if (nInner + nPrim == 0) break;  // every lane idle and the queue exhausted
     }
     // a phase ends once its lanes have fallen to 3/8 (INNER) or 1/8 (PRIM) of the lanes that had work at the vote:
