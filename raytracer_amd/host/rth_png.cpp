@@ -66,7 +66,7 @@ bool decodePNG8(const std::string &filename, int &w, int &h, std::vector<uint8_t
     pos += 12 + (size_t)len;
   }
   if (!seenIHDR || w <= 0 || h <= 0) { error = "PNG without a valid IHDR"; return false; }
-  if (interlace != 0) { error = "interlaced PNG is not supported"; return false; }
+  if (interlace != 0 && interlace != 1) { error = "bad PNG interlace method"; return false; }
   int channels;
   switch (colorType) {
     case 0: channels = 1; break;
@@ -76,35 +76,24 @@ bool decodePNG8(const std::string &filename, int &w, int &h, std::vector<uint8_t
     case 6: channels = 4; break;
     default: error = "bad PNG colour type"; return false;
   }
-  int bitsPerPixel = channels * bitDepth;
-  size_t rowBytes = ((size_t)w * bitsPerPixel + 7) / 8;
-  int bpp = std::max(1, bitsPerPixel / 8);
-  std::vector<uint8_t> raw((rowBytes + 1) * (size_t)h);
+  const int bitsPerPixel = channels * bitDepth;
+  const int bpp = std::max(1, bitsPerPixel / 8);
+  auto rowBytesOf = [&](int pixels) { return ((size_t)pixels * bitsPerPixel + 7) / 8; };
+  // sub-images: the whole image, or the seven Adam7 passes (x start, y start, x step, y step)
+  struct Pass { int x0, y0, dx, dy; };
+  static const Pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+  static const Pass whole[1] = {{0, 0, 1, 1}};
+  const Pass *passes = interlace ? adam7 : whole;
+  const int numPasses = interlace ? 7 : 1;
+  size_t rawSize = 0;
+  for (int p = 0; p < numPasses; ++p) {
+    int pw = (w - passes[p].x0 + passes[p].dx - 1) / passes[p].dx, ph = (h - passes[p].y0 + passes[p].dy - 1) / passes[p].dy;
+    if (pw > 0 && ph > 0) rawSize += (rowBytesOf(pw) + 1) * (size_t)ph;
+  }
+  std::vector<uint8_t> raw(rawSize);
   uLongf rawLen = (uLongf)raw.size();
   int zr = uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size());
   if (zr != Z_OK || rawLen != raw.size()) { error = "PNG inflate failed"; return false; }
-  // undo the per-row filters in place
-  std::vector<uint8_t> prev(rowBytes, 0), cur(rowBytes);
-  std::vector<uint8_t> pix(rowBytes * (size_t)h);
-  for (int y = 0; y < h; ++y) {
-    const uint8_t *row = &raw[(rowBytes + 1) * (size_t)y];
-    int ft = row[0];
-    for (size_t i = 0; i < rowBytes; ++i) {
-      int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= (size_t)bpp ? prev[i - bpp] : 0;
-      int x = row[1 + i];
-      switch (ft) {
-        case 0: break;
-        case 1: x += a; break;
-        case 2: x += b; break;
-        case 3: x += (a + b) >> 1; break;
-        case 4: x += paeth(a, b, c); break;
-        default: error = "bad PNG filter type"; return false;
-      }
-      cur[i] = (uint8_t)x;
-    }
-    std::memcpy(&pix[rowBytes * (size_t)y], cur.data(), rowBytes);
-    prev.swap(cur);
-  }
   rgba8.assign((size_t)w * h * 4, 255);
   auto sample = [&](const uint8_t *row, int idx) -> unsigned {  // idx-th sample of the row, full bit depth
     if (bitDepth == 8) return row[idx];
@@ -112,36 +101,61 @@ bool decodePNG8(const std::string &filename, int &w, int &h, std::vector<uint8_t
     int bitPos = idx * bitDepth;
     return (row[bitPos >> 3] >> (8 - bitDepth - (bitPos & 7))) & ((1u << bitDepth) - 1);
   };
-  unsigned maxv = (1u << bitDepth) - 1;
+  const unsigned maxv = (1u << bitDepth) - 1;
   auto to8 = [&](unsigned v) -> uint8_t {
     if (bitDepth == 8) return (uint8_t)v;
     if (bitDepth == 16) return (uint8_t)(v >> 8);
     return (uint8_t)((v * 255u) / maxv);
   };
-  for (int y = 0; y < h; ++y) {
-    const uint8_t *row = &pix[rowBytes * (size_t)y];
-    for (int x = 0; x < w; ++x) {
-      uint8_t *o = &rgba8[((size_t)y * w + x) * 4];
-      if (colorType == 0) {
-        unsigned g = sample(row, x);
-        o[0] = o[1] = o[2] = to8(g);
-        if (trns.size() >= 2 && g == ((unsigned)trns[0] << 8 | trns[1])) o[3] = 0;
-      } else if (colorType == 2) {
-        unsigned r = sample(row, x * 3), g = sample(row, x * 3 + 1), b = sample(row, x * 3 + 2);
-        o[0] = to8(r); o[1] = to8(g); o[2] = to8(b);
-        if (trns.size() >= 6 && r == ((unsigned)trns[0] << 8 | trns[1]) && g == ((unsigned)trns[2] << 8 | trns[3]) &&
-            b == ((unsigned)trns[4] << 8 | trns[5])) o[3] = 0;
-      } else if (colorType == 3) {
-        unsigned i = sample(row, x);
-        if ((size_t)i * 3 + 2 < palette.size()) { o[0] = palette[i * 3]; o[1] = palette[i * 3 + 1]; o[2] = palette[i * 3 + 2]; }
-        else { o[0] = o[1] = o[2] = 0; }
-        if (i < trns.size()) o[3] = trns[i];
-      } else if (colorType == 4) {
-        o[0] = o[1] = o[2] = to8(sample(row, x * 2)); o[3] = to8(sample(row, x * 2 + 1));
-      } else {
-        o[0] = to8(sample(row, x * 4)); o[1] = to8(sample(row, x * 4 + 1));
-        o[2] = to8(sample(row, x * 4 + 2)); o[3] = to8(sample(row, x * 4 + 3));
+  auto emit = [&](const uint8_t *row, int x, uint8_t *o) {  // pixel x of an unfiltered row -> 8-bit RGBA
+    if (colorType == 0) {
+      unsigned g = sample(row, x);
+      o[0] = o[1] = o[2] = to8(g);
+      if (trns.size() >= 2 && g == ((unsigned)trns[0] << 8 | trns[1])) o[3] = 0;
+    } else if (colorType == 2) {
+      unsigned r = sample(row, x * 3), g = sample(row, x * 3 + 1), b = sample(row, x * 3 + 2);
+      o[0] = to8(r); o[1] = to8(g); o[2] = to8(b);
+      if (trns.size() >= 6 && r == ((unsigned)trns[0] << 8 | trns[1]) && g == ((unsigned)trns[2] << 8 | trns[3]) &&
+          b == ((unsigned)trns[4] << 8 | trns[5])) o[3] = 0;
+    } else if (colorType == 3) {
+      unsigned i = sample(row, x);
+      if ((size_t)i * 3 + 2 < palette.size()) { o[0] = palette[i * 3]; o[1] = palette[i * 3 + 1]; o[2] = palette[i * 3 + 2]; }
+      else { o[0] = o[1] = o[2] = 0; }
+      if (i < trns.size()) o[3] = trns[i];
+    } else if (colorType == 4) {
+      o[0] = o[1] = o[2] = to8(sample(row, x * 2)); o[3] = to8(sample(row, x * 2 + 1));
+    } else {
+      o[0] = to8(sample(row, x * 4)); o[1] = to8(sample(row, x * 4 + 1));
+      o[2] = to8(sample(row, x * 4 + 2)); o[3] = to8(sample(row, x * 4 + 3));
+    }
+  };
+  size_t at = 0;
+  for (int p = 0; p < numPasses; ++p) {
+    const Pass &ps = passes[p];
+    const int pw = (w - ps.x0 + ps.dx - 1) / ps.dx, ph = (h - ps.y0 + ps.dy - 1) / ps.dy;
+    if (pw <= 0 || ph <= 0) continue;
+    const size_t rowBytes = rowBytesOf(pw);
+    std::vector<uint8_t> prev(rowBytes, 0), cur(rowBytes);
+    for (int y = 0; y < ph; ++y) {
+      const uint8_t *row = &raw[at];
+      at += rowBytes + 1;
+      const int ft = row[0];
+      for (size_t i = 0; i < rowBytes; ++i) {  // undo the row filter
+        int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= (size_t)bpp ? prev[i - bpp] : 0;
+        int x = row[1 + i];
+        switch (ft) {
+          case 0: break;
+          case 1: x += a; break;
+          case 2: x += b; break;
+          case 3: x += (a + b) >> 1; break;
+          case 4: x += paeth(a, b, c); break;
+          default: error = "bad PNG filter type"; return false;
+        }
+        cur[i] = (uint8_t)x;
       }
+      const int oy = ps.y0 + y * ps.dy;
+      for (int x = 0; x < pw; ++x) emit(cur.data(), x, &rgba8[((size_t)oy * w + ps.x0 + (size_t)x * ps.dx) * 4]);
+      prev.swap(cur);
     }
   }
   return true;

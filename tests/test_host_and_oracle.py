@@ -97,6 +97,18 @@ def test_oracle_counter_mode_converges_to_reference_stream(scene_path, golden):
     assert psnr(img[..., :3], g["render_f32"][..., :3]) > 20.0
 
 
+def test_png_decoder_matches_reference_on_every_png_kind(tmp_path, golden):
+    """All colour types and bit depths, plain and Adam7-interlaced, the five row filters, palettes, tRNS, several IDAT
+    chunks: what PNG::readFromFile leaves in memory in the reference (hashes from the compiled reference)."""
+    from tools import png_variants
+    g = golden("png_variants")
+    names = png_variants.write_all(str(tmp_path))
+    assert names == [str(n) for n in g["names"]]
+    for n, want in zip(names, g["decoded"]):
+        img = capi.png_read_linear(str(tmp_path / n))
+        assert f"{img.shape[1]}x{img.shape[0]}:{sha1(img)}" == str(want), n
+
+
 def test_png_pixels_roundtrip(tmp_path):
     rng = np.random.default_rng(0)
     rgba8 = rng.integers(0, 256, size=(37, 53, 4), dtype=np.uint8)
