@@ -58,6 +58,15 @@ bool decodePNG8(const std::string &filename, int &w, int &h, std::vector<uint8_t
       if (len != 13) { error = "bad IHDR"; return false; }
       w = (int)be32(data); h = (int)be32(data + 4);
       bitDepth = data[8]; colorType = data[9]; interlace = data[12];
+      // Only the combinations of the PNG specification's table: anything else would shift by a negative or
+      // oversized amount, or divide by zero, below. LodePNG reports a decoder error for them too.
+      const bool depthOk = colorType == 0   ? (bitDepth == 1 || bitDepth == 2 || bitDepth == 4 || bitDepth == 8 || bitDepth == 16)
+                           : colorType == 3 ? (bitDepth == 1 || bitDepth == 2 || bitDepth == 4 || bitDepth == 8)
+                           : (colorType == 2 || colorType == 4 || colorType == 6) ? (bitDepth == 8 || bitDepth == 16)
+                                                                                  : false;
+      if (!depthOk) { error = "bad PNG colour type / bit depth"; return false; }
+      if (data[10] != 0 || data[11] != 0) { error = "bad PNG compression or filter method"; return false; }
+      if (w <= 0 || h <= 0 || (uint64_t)w * (uint64_t)h > ((uint64_t)1 << 28)) { error = "bad PNG size"; return false; }
       seenIHDR = true;
     } else if (!std::memcmp(type, "PLTE", 4)) palette.assign(data, data + len);
     else if (!std::memcmp(type, "tRNS", 4)) trns.assign(data, data + len);

@@ -126,6 +126,44 @@ def test_png_pixels_roundtrip(tmp_path):
     assert np.array_equal(capi.to_srgb8(lin), rgba8)
 
 
+def _png_with_ihdr(path, width, height, depth, ctype, compression=0, flt=0, interlace=0):
+    import struct
+    import zlib
+
+    def chunk(kind, data):
+        return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xFFFFFFFF)
+    ihdr = struct.pack(">IIBBBBB", width & 0xFFFFFFFF, height & 0xFFFFFFFF, depth, ctype, compression, flt, interlace)
+    body = zlib.compress(b"\0" * 64)
+    open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", body) + chunk(b"IEND", b""))
+
+
+def test_malformed_png_headers_are_errors_not_crashes(tmp_path):
+    """Bit depths outside the PNG table (0 would divide by zero, 3 or 32 would shift out of range), unknown colour
+    types, non-zero compression/filter methods and absurd sizes: a decoder error like LodePNG's, and a scene that
+    names such a texture carries on with an empty image like Scene::loadTexture (src/scene/raytracer.h) does."""
+    bad = [dict(depth=0, ctype=0), dict(depth=3, ctype=0), dict(depth=32, ctype=2), dict(depth=4, ctype=2), dict(depth=16, ctype=3),
+           dict(depth=2, ctype=6), dict(depth=8, ctype=5), dict(depth=8, ctype=6, compression=1), dict(depth=8, ctype=6, flt=1),
+           dict(depth=8, ctype=6, interlace=2)]
+    for i, kw in enumerate(bad):
+        p = str(tmp_path / f"bad{i}.png")
+        _png_with_ihdr(p, 4, 4, **kw)
+        with pytest.raises(RuntimeError, match="PNG"):
+            capi.png_read_linear(p)
+        with pytest.raises(RuntimeError, match="PNG"):
+            capi.png_read_rgba8(p)
+    for w, h in ((0, 4), (4, 0), (0x7FFFFFFF, 0x7FFFFFFF), (0xFFFFFFFF, 1)):
+        p = str(tmp_path / "size.png")
+        _png_with_ihdr(p, w, h, 8, 6)
+        with pytest.raises(RuntimeError, match="PNG"):
+            capi.png_read_linear(p)
+    p = str(tmp_path / "bad0.png")
+    hs = capi.HostScene.new(8, 8)
+    L = capi.load_host_library()
+    idx = L.rth_scene_add_texture_file(hs._h, p.encode())
+    assert idx >= 0  # an empty texture, logged, not an exception across the C boundary
+    assert any("PNG" in line for line in hs.log)
+
+
 def test_scene_errors(tmp_path):
     with pytest.raises(RuntimeError, match="Couldn't open file"):
         capi.HostScene.load(str(tmp_path / "missing.sdml"))
