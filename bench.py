@@ -2,7 +2,7 @@
 """Headline benchmark: Mrays/s and frame wall-time of the README-scene stand-in (1080x1080, 256 camera samples per
 pixel, ~1.05 M triangles + 2 textured spheres + 3 textured planes, point + environment light, maxBounces 4).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]      (N > 1: starts the N ranks itself, as a child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A step is one whole frame through the C ABI (rt_render): scene and BVH already resident in HBM, the frame left in a
@@ -86,8 +86,29 @@ def bytes_per_ray(inner, prims, rays):
     return 32.0 + 64.0 * inner / rays + 48.0 * prims / rays + 16.0
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: this process (which has not touched the GPU and
+    never will) starts the N ranks with torch.distributed.run as a CHILD process, relays what they print and exits with
+    their code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            raise SystemExit(launch_ranks(args))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -95,6 +116,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("RT_BENCH_DRY_RUN"):
+        # launcher rehearsal for boxes without a GPU: rendezvous over gloo, nothing rendered, nothing measured
+        if world > 1:
+            dist.init_process_group("gloo")
+            seen = torch.ones(1)
+            dist.all_reduce(seen)
+            assert int(seen[0]) == world
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup}), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render loop has no CPU fallback")
     # RT_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: ranks share the GPUs there are

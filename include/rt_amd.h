@@ -179,12 +179,13 @@ int rt_scene_set_view(RtScene *scene, const RtCamera *camera, const RtOptions *o
 /* Primary-ray closest hits for the pixel rectangle [x0,x0+w) x [y0,y0+h), un-jittered pixel centres
  * (the numRays == 1 form of src/scene/raytracer.cpp:44-47 followed by Scene::findClosestObject, :187-196).
  * primId[j] = original insertion index of the hit object, numPrims + k for plane k, -1 for a miss;
- * t[j] = IntersectionInfo::t (+inf on a miss). Row-major over the rectangle; host buffers. */
+ * t[j] = IntersectionInfo::t (+inf on a miss). Row-major over the rectangle; host or device buffers. */
 int rt_trace_primary(RtScene *scene, int32_t x0, int32_t y0, int32_t w, int32_t h, int32_t *primId, float *t);
 
 /* Scene::findClosestObject (src/scene/raytracer.cpp:187-196) for n arbitrary rays.
  * origins/directions: [n*3] host floats, directions un-normalised as the reference passes them.
- * Outputs (host, any may be NULL): primId[n], t[n], point[n*3], normal[n*3]. */
+ * Outputs (host or device memory, any may be NULL): primId[n], t[n], point[n*3], normal[n*3]. The device-side staging of
+ * the trace entry points belongs to the scene and only grows: a repeated call of the same size allocates nothing. */
 int rt_trace_closest(RtScene *scene, int64_t n, const float *origins, const float *directions,
                      int32_t *primId, float *t, float *point, float *normal);
 
@@ -208,6 +209,12 @@ const float *rt_framebuffer_device(RtScene *scene);
  * the join of the reference's worker threads (src/scene/raytracer.cpp:276-279), which write into one shared image. */
 int rt_framebuffer_add(RtScene *dst, RtScene *src);
 
+/* The same for several sources at once: each source's own pixels (its partition only, 16 bytes per pixel, kept packed
+ * by its rt_render) are copied device to device into staging buffers that `dst` keeps between calls and added into
+ * dst's framebuffer. Peer access between the devices is enabled on first use, every source's copy runs on a stream of
+ * its own (a different xGMI link per peer), and the call returns after one synchronisation. */
+int rt_framebuffer_gather(RtScene *dst, RtScene *const *srcs, int32_t numSrcs);
+
 /* Copies the float RGBA framebuffer of the last rt_render (after any rt_framebuffer_add) to rgbaOut
  * (width*height*4 floats, host or device memory). */
 int rt_framebuffer_read(RtScene *scene, float *rgbaOut);
@@ -215,6 +222,10 @@ int rt_framebuffer_read(RtScene *scene, float *rgbaOut);
 /* PNG::saveToFile's pixel conversion (src/image/PNG.cpp:149-157): sRGB transfer + round(c*255), on the
  * device, from the framebuffer of the last rt_render; rgba8Out: width*height*4 bytes (host). */
 int rt_resolve_rgba8(RtScene *scene, uint8_t *rgba8Out);
+
+/* Device time (HIP events on the scene's stream) of the traversal kernel of the last rt_trace_primary / rt_trace_closest /
+ * rt_trace_any call on this scene, in milliseconds; copies not included. */
+float rt_last_trace_kernel_ms(RtScene *scene);
 
 const char *rt_last_error(void);
 const char *rt_version(void);

@@ -981,6 +981,12 @@ int rto_framebuffer_add(RtoScene *dst, RtoScene *src) {  // host mirror of rt_fr
   return RT_OK;
 }
 
+int rto_framebuffer_gather(RtoScene *dst, RtoScene *const *srcs, int32_t numSrcs) {  // host mirror of rt_framebuffer_gather
+  for (int32_t i = 0; i < numSrcs; ++i)
+    if (int rc = rto_framebuffer_add(dst, srcs[i])) return rc;
+  return RT_OK;
+}
+
 int rto_framebuffer_read(RtoScene *s, float *out) {
   if (!s || !out) return fail("null argument");
   std::copy(s->framebuffer.begin(), s->framebuffer.end(), out);

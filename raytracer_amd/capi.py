@@ -325,6 +325,9 @@ def bind_render_abi(L, prefix):
     fn("framebuffer_device").restype = vp; fn("framebuffer_device").argtypes = [vp]
     fn("resolve_rgba8").argtypes = [vp, C.POINTER(C.c_uint8)]
     fn("framebuffer_add").argtypes = [vp, vp]
+    fn("framebuffer_gather").argtypes = [vp, C.POINTER(vp), i32]
+    if hasattr(L, prefix + "last_trace_kernel_ms"):  # HIP library only
+        fn("last_trace_kernel_ms").restype = C.c_float; fn("last_trace_kernel_ms").argtypes = [vp]
     fn("framebuffer_read").argtypes = [vp, f32p]
     fn("device_count").restype = C.c_int
     fn("last_error").restype = C.c_char_p
@@ -413,6 +416,14 @@ class RenderScene:
     def framebuffer_add(self, other):
         """Adds `other`'s last frame to this scene's (device to device): the gather of disjoint tile partitions."""
         self._check(self._f("framebuffer_add")(self._h, other._h), "framebuffer_add")
+
+    def framebuffer_gather(self, others):
+        """Adds the last frames of `others` (disjoint tile partitions) to this scene's in one call."""
+        arr = (C.c_void_p * len(others))(*[o._h for o in others])
+        self._check(self._f("framebuffer_gather")(self._h, arr, len(others)), "framebuffer_gather")
+
+    def last_trace_kernel_ms(self):
+        return float(self._f("last_trace_kernel_ms")(self._h))
 
     def framebuffer_read(self):
         out = np.empty((self.height, self.width, 4), dtype=np.float32)

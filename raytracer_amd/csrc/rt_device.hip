@@ -410,7 +410,6 @@ __global__ void k_begin_pass(PathBuf B, uint32_t nActive) {
   c->nActive = nActive; c->nNext = 0; c->nHit = 0;
   c->ticket[0].next = 0; c->ticket[1].next = 0;
 }
-__global__ void k_reset_trace_ticket(Counts *c) { c->ticket[2].next = 0; }
 __global__ void k_count_samples(PathBuf B, unsigned long long n) { B.counts->samples += n; }  // rejected fisheye samples count too
 
 // Per pixel: fold this pass's samples, in sample order, into the running sum (raytracer.cpp:48-51).
@@ -432,7 +431,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PathBuf B, float4 *pixSum
 
 // raytracer.cpp:54-59 then Scene::expose (:303-312)
 __global__ __launch_bounds__(kBlock) void k_resolve(DevScene S, int32_t npix, const int32_t *pixList, const float4 *pixSum,
-                                                    const int32_t *pixHits, float4 *fb, int32_t applyExposure) {
+                                                    const int32_t *pixHits, float4 *fb, float4 *packed, int32_t applyExposure) {
   int32_t p = blockIdx.x * kBlock + threadIdx.x;
   if (p >= npix) return;
   RGBA avg = rgba(pixSum[p]);
@@ -451,6 +450,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DevScene S, int32_t npix, co
     c.b = (float)(1.0 - (double)expf(-1 * c.b * S.exposure));
   }
   fb[pixList[p]] = f4(c);
+  packed[p] = f4(c);
 }
 
 // PNG::saveToFile's conversion, src/image/PNG.cpp:7-12, 149-157
@@ -458,12 +458,15 @@ RT_DEV float linearToGamma(float channel) {
   if ((double)channel < 0.0031308) return (float)(12.92 * (double)channel);
   return (float)(1.055 * pow((double)channel, 1 / 2.4) - 0.055);
 }
-// dst += src, component by component: tile partitions own disjoint pixels and leave the others exactly 0
-__global__ __launch_bounds__(kBlock) void k_add_frame(float4 *dst, const float4 *src, int64_t n) {
+// fb[idx[i]] += src[i], component by component: tile partitions own disjoint pixels and a frame holds exact zeros
+// outside its own partition, so the sum is the other partition's value, bit for bit
+__global__ __launch_bounds__(kBlock) void k_scatter_add(float4 *fb, const float4 *src, const int32_t *idx, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  float4 a = dst[i], b = src[i];
-  dst[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  float4 b = src[i];
+  float4 *d = fb + idx[i];
+  float4 a = *d;
+  *d = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
 
 __global__ __launch_bounds__(kBlock) void k_srgb8(const float4 *fb, uchar4 *out, int32_t n) {
@@ -515,12 +518,11 @@ struct PrimarySource {
 };
 
 __global__ __launch_bounds__(kBlock) void k_trace_primary(DevScene S, int32_t x0, int32_t y0, int32_t w, int32_t h,
-                                                          int32_t *outPrim, float *outT, Counts *counts) {
+                                                          int32_t *outPrim, float *outT, uint32_t *ticket) {
   __shared__ uint2 ldsStack[kStackLds * kBlock];
   TravCounters tc = {0, 0, 0, 0.0f, 0.0f};
   PrimarySource src{S, x0, y0, w, h, outPrim, outT};
-  traverseQueue<PrimarySource, false, false, kStackLds, kBlock>(S, src, &counts->ticket[2].next, ldsStack, tc);
-  flushCounters<false>(counts, tc, 0);
+  traverseQueue<PrimarySource, false, false, kStackLds, kBlock>(S, src, ticket, ldsStack, tc);
 }
 
 template <bool ANY>
@@ -569,12 +571,11 @@ struct RaysSource {
 template <bool ANY>
 __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene S, int64_t n, const float *origins, const float *directions,
                                                        int32_t *outPrim, float *outT, float *outPoint, float *outNormal,
-                                                       uint8_t *outOccluded, Counts *counts) {
+                                                       uint8_t *outOccluded, uint32_t *ticket) {
   __shared__ uint2 ldsStack[kStackLds * kBlock];
   TravCounters tc = {0, 0, 0, 0.0f, 0.0f};
   RaysSource<ANY> src{S, n, origins, directions, outPrim, outT, outPoint, outNormal, outOccluded};
-  traverseQueue<RaysSource<ANY>, ANY, false, kStackLds, kBlock>(S, src, &counts->ticket[2].next, ldsStack, tc);
-  flushCounters<false>(counts, tc, 0);
+  traverseQueue<RaysSource<ANY>, ANY, false, kStackLds, kBlock>(S, src, ticket, ldsStack, tc);
 }
 
 // ---------------------------------------------------------------------------------------------------- host side
@@ -599,6 +600,15 @@ enum { CAT_RAYGEN, CAT_EXTEND, CAT_SHADE, CAT_SHADOW, CAT_DIRECT, CAT_ACCUM, CAT
 
 }  // namespace
 
+struct PeerSlot {  // destination-side state of a gather from one other scene
+  int key[6] = {-1, -1, -1, -1, -1, -1};
+  int32_t *idx = nullptr;
+  float4 *staging = nullptr;
+  int64_t cap = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+};
+
 struct RtScene {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -616,13 +626,21 @@ struct RtScene {
   float4 *pixSum = nullptr;
   int32_t *pixHits = nullptr;
   float4 *fb = nullptr;
+  float4 *packed = nullptr;  // this partition's resolved pixels in pixel-list order: what a gather moves to another GPU
   int64_t fbPixels = 0, pixCap = 0;
   // the pixel list on the device belongs to this partition (a repeated frame does not rebuild and re-upload it)
   int pixKey[6] = {-1, -1, -1, -1, -1, -1};
   int64_t pixCount = 0;
   Counts *counts = nullptr;
+  // staging of the trace-only and conversion entry points: grow-only, so a repeated call of the same size allocates nothing
+  void *work = nullptr;
+  size_t workBytes = 0;
+  hipEvent_t workEvA = nullptr, workEvB = nullptr;
+  float lastKernelMs = 0.0f;
   std::vector<EventPair> events;
   size_t eventsUsed = 0;
+  std::vector<PeerSlot> peers;
+  std::vector<int> peerEnabled;
 };
 
 namespace {
@@ -916,11 +934,13 @@ int ensureRenderBuffers(RtScene *s, int64_t P, int64_t npix, int64_t fbPixels) {
     if (s->pixList) (void)hipFree(s->pixList);
     if (s->pixSum) (void)hipFree(s->pixSum);
     if (s->pixHits) (void)hipFree(s->pixHits);
-    s->pixList = nullptr; s->pixSum = nullptr; s->pixHits = nullptr;
+    if (s->packed) (void)hipFree(s->packed);
+    s->pixList = nullptr; s->pixSum = nullptr; s->pixHits = nullptr; s->packed = nullptr;
     s->pixKey[0] = -1;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->pixList), npix * sizeof(int32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->pixSum), npix * sizeof(float4)));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->pixHits), npix * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->packed), npix * sizeof(float4)));
     s->pixCap = npix;
   }
   if (s->arenaP < P) {
@@ -1033,6 +1053,16 @@ void rt_scene_destroy(RtScene *s) {
   if (s->pixSum) (void)hipFree(s->pixSum);
   if (s->pixHits) (void)hipFree(s->pixHits);
   if (s->fb) (void)hipFree(s->fb);
+  if (s->packed) (void)hipFree(s->packed);
+  if (s->work) (void)hipFree(s->work);
+  if (s->workEvA) (void)hipEventDestroy(s->workEvA);
+  if (s->workEvB) (void)hipEventDestroy(s->workEvB);
+  for (auto &ps : s->peers) {
+    if (ps.stream) { (void)hipStreamSynchronize(ps.stream); (void)hipStreamDestroy(ps.stream); }
+    if (ps.done) (void)hipEventDestroy(ps.done);
+    if (ps.idx) (void)hipFree(ps.idx);
+    if (ps.staging) (void)hipFree(ps.staging);
+  }
   for (auto &e : s->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
@@ -1056,27 +1086,48 @@ int rt_scene_set_view(RtScene *s, const RtCamera *camera, const RtOptions *optio
   return RT_OK;
 }
 
+// Staging for the trace-only entry points (device side of the host buffers the caller passes). It only ever grows:
+// a caller that repeats a call of the same size pays for no allocation after the first.
+static int ensureWork(RtScene *s, size_t bytes) {
+  if (s->workBytes >= bytes) return RT_OK;
+  if (s->work) { (void)hipFree(s->work); s->work = nullptr; s->workBytes = 0; }
+  bytes = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+  HIP_TRY(hipMalloc(&s->work, bytes));
+  s->workBytes = bytes;
+  return RT_OK;
+}
+static int ensureWorkEvents(RtScene *s) {
+  if (!s->workEvA) HIP_TRY(hipEventCreate(&s->workEvA));
+  if (!s->workEvB) HIP_TRY(hipEventCreate(&s->workEvB));
+  return RT_OK;
+}
+static inline size_t alignUp256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Un-jittered primary rays of the rectangle into device arrays outPrim / outT, queue ticket at `ticket` (device word).
+static void launchTracePrimary(RtScene *s, int32_t x0, int32_t y0, int32_t w, int32_t h, int32_t *outPrim, float *outT, uint32_t *ticket) {
+  int64_t waves = (int64_t)((w + 7) / 8) * ((h + 7) / 8);
+  k_trace_primary<<<persistentGrid(s, waves * 64), kBlock, 0, s->stream>>>(s->dev, x0, y0, w, h, outPrim, outT, ticket);
+}
+
 int rt_trace_primary(RtScene *s, int32_t x0, int32_t y0, int32_t w, int32_t h, int32_t *primId, float *t) {
   if (!s || !primId || !t) return failMsg(RT_ERR_INVALID, "null argument");
   if (w <= 0 || h <= 0) return failMsg(RT_ERR_INVALID, "empty rectangle");
   HIP_TRY(hipSetDevice(s->device));
   int64_t n = (int64_t)w * h;
-  int32_t *dPrim = nullptr;
-  float *dT = nullptr;
-  hipError_t e = hipMalloc(reinterpret_cast<void **>(&dPrim), n * 4);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dT), n * 4);
-  if (e == hipSuccess) {
-    int64_t waves = (int64_t)((w + 7) / 8) * ((h + 7) / 8);
-    k_reset_trace_ticket<<<1, 1, 0, s->stream>>>(s->counts);
-    k_trace_primary<<<persistentGrid(s, waves * 64), kBlock, 0, s->stream>>>(s->dev, x0, y0, w, h, dPrim, dT, s->counts);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipMemcpyAsync(primId, dPrim, n * 4, hipMemcpyDeviceToHost, s->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(t, dT, n * 4, hipMemcpyDeviceToHost, s->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-  if (dPrim) (void)hipFree(dPrim);
-  if (dT) (void)hipFree(dT);
-  if (e != hipSuccess) return failMsg(RT_ERR_DEVICE, std::string("rt_trace_primary: ") + hipGetErrorString(e));
+  int rc;
+  if ((rc = ensureWork(s, 2 * alignUp256((size_t)n * 4)))) return rc;
+  if ((rc = ensureWorkEvents(s))) return rc;
+  int32_t *dPrim = static_cast<int32_t *>(s->work);
+  float *dT = reinterpret_cast<float *>(static_cast<char *>(s->work) + alignUp256((size_t)n * 4));
+  HIP_TRY(hipMemsetAsync(&s->counts->ticket[2].next, 0, sizeof(uint32_t), s->stream));
+  HIP_TRY(hipEventRecord(s->workEvA, s->stream));
+  launchTracePrimary(s, x0, y0, w, h, dPrim, dT, &s->counts->ticket[2].next);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(s->workEvB, s->stream));
+  HIP_TRY(hipMemcpyAsync(primId, dPrim, n * 4, hipMemcpyDefault, s->stream));
+  HIP_TRY(hipMemcpyAsync(t, dT, n * 4, hipMemcpyDefault, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipEventElapsedTime(&s->lastKernelMs, s->workEvA, s->workEvB));
   return RT_OK;
 }
 
@@ -1084,38 +1135,41 @@ static int traceRays(RtScene *s, bool any, int64_t n, const float *origins, cons
                      float *point, float *normal, uint8_t *occluded) {
   if (!s || !origins || !directions) return failMsg(RT_ERR_INVALID, "null argument");
   if (n <= 0) return RT_OK;
+  if (n >= ((int64_t)1 << 32) - ((int64_t)1 << 24)) return failMsg(RT_ERR_INVALID, "too many rays for one call (queue indices are 32-bit)");
   HIP_TRY(hipSetDevice(s->device));
-  float *dO = nullptr, *dD = nullptr, *dT = nullptr, *dP = nullptr, *dN = nullptr;
-  int32_t *dPrim = nullptr;
-  uint8_t *dOcc = nullptr;
-  std::vector<void *> tmp;
-  auto alloc = [&](void **p, size_t bytes) { hipError_t e = hipMalloc(p, bytes); if (e == hipSuccess) tmp.push_back(*p); return e; };
-  hipError_t e = alloc(reinterpret_cast<void **>(&dO), n * 12);
-  if (e == hipSuccess) e = alloc(reinterpret_cast<void **>(&dD), n * 12);
-  if (any) {
-    if (e == hipSuccess) e = alloc(reinterpret_cast<void **>(&dOcc), n);
-  } else {
-    if (e == hipSuccess && primId) e = alloc(reinterpret_cast<void **>(&dPrim), n * 4);
-    if (e == hipSuccess && t) e = alloc(reinterpret_cast<void **>(&dT), n * 4);
-    if (e == hipSuccess && point) e = alloc(reinterpret_cast<void **>(&dP), n * 12);
-    if (e == hipSuccess && normal) e = alloc(reinterpret_cast<void **>(&dN), n * 12);
-  }
-  if (e == hipSuccess) e = hipMemcpyAsync(dO, origins, n * 12, hipMemcpyHostToDevice, s->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(dD, directions, n * 12, hipMemcpyHostToDevice, s->stream);
-  if (e == hipSuccess) {
-    k_reset_trace_ticket<<<1, 1, 0, s->stream>>>(s->counts);
-    if (any) k_trace_rays<true><<<persistentGrid(s, n), kBlock, 0, s->stream>>>(s->dev, n, dO, dD, nullptr, nullptr, nullptr, nullptr, dOcc, s->counts);
-    else k_trace_rays<false><<<persistentGrid(s, n), kBlock, 0, s->stream>>>(s->dev, n, dO, dD, dPrim, dT, dP, dN, nullptr, s->counts);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess && dOcc) e = hipMemcpyAsync(occluded, dOcc, n, hipMemcpyDeviceToHost, s->stream);
-  if (e == hipSuccess && dPrim) e = hipMemcpyAsync(primId, dPrim, n * 4, hipMemcpyDeviceToHost, s->stream);
-  if (e == hipSuccess && dT) e = hipMemcpyAsync(t, dT, n * 4, hipMemcpyDeviceToHost, s->stream);
-  if (e == hipSuccess && dP) e = hipMemcpyAsync(point, dP, n * 12, hipMemcpyDeviceToHost, s->stream);
-  if (e == hipSuccess && dN) e = hipMemcpyAsync(normal, dN, n * 12, hipMemcpyDeviceToHost, s->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-  for (void *p : tmp) (void)hipFree(p);
-  if (e != hipSuccess) return failMsg(RT_ERR_DEVICE, std::string("rt_trace: ") + hipGetErrorString(e));
+  // carve the staging area: origins, directions, then whichever outputs were asked for
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t at = off; off += alignUp256(bytes); return at; };
+  const size_t oO = carve((size_t)n * 12), oD = carve((size_t)n * 12);
+  const size_t oOcc = any ? carve((size_t)n) : 0;
+  const size_t oPrim = (!any && primId) ? carve((size_t)n * 4) : 0, oT = (!any && t) ? carve((size_t)n * 4) : 0;
+  const size_t oP = (!any && point) ? carve((size_t)n * 12) : 0, oN = (!any && normal) ? carve((size_t)n * 12) : 0;
+  int rc;
+  if ((rc = ensureWork(s, off))) return rc;
+  if ((rc = ensureWorkEvents(s))) return rc;
+  char *base = static_cast<char *>(s->work);
+  float *dO = reinterpret_cast<float *>(base + oO), *dD = reinterpret_cast<float *>(base + oD);
+  uint8_t *dOcc = any ? reinterpret_cast<uint8_t *>(base + oOcc) : nullptr;
+  int32_t *dPrim = (!any && primId) ? reinterpret_cast<int32_t *>(base + oPrim) : nullptr;
+  float *dT = (!any && t) ? reinterpret_cast<float *>(base + oT) : nullptr;
+  float *dP = (!any && point) ? reinterpret_cast<float *>(base + oP) : nullptr;
+  float *dN = (!any && normal) ? reinterpret_cast<float *>(base + oN) : nullptr;
+  uint32_t *ticket = &s->counts->ticket[2].next;
+  HIP_TRY(hipMemcpyAsync(dO, origins, n * 12, hipMemcpyDefault, s->stream));
+  HIP_TRY(hipMemcpyAsync(dD, directions, n * 12, hipMemcpyDefault, s->stream));
+  HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(uint32_t), s->stream));
+  HIP_TRY(hipEventRecord(s->workEvA, s->stream));
+  if (any) k_trace_rays<true><<<persistentGrid(s, n), kBlock, 0, s->stream>>>(s->dev, n, dO, dD, nullptr, nullptr, nullptr, nullptr, dOcc, ticket);
+  else k_trace_rays<false><<<persistentGrid(s, n), kBlock, 0, s->stream>>>(s->dev, n, dO, dD, dPrim, dT, dP, dN, nullptr, ticket);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(s->workEvB, s->stream));
+  if (dOcc) HIP_TRY(hipMemcpyAsync(occluded, dOcc, n, hipMemcpyDefault, s->stream));
+  if (dPrim) HIP_TRY(hipMemcpyAsync(primId, dPrim, n * 4, hipMemcpyDefault, s->stream));
+  if (dT) HIP_TRY(hipMemcpyAsync(t, dT, n * 4, hipMemcpyDefault, s->stream));
+  if (dP) HIP_TRY(hipMemcpyAsync(point, dP, n * 12, hipMemcpyDefault, s->stream));
+  if (dN) HIP_TRY(hipMemcpyAsync(normal, dN, n * 12, hipMemcpyDefault, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipEventElapsedTime(&s->lastKernelMs, s->workEvA, s->workEvB));
   return RT_OK;
 }
 
@@ -1190,6 +1244,9 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
     }
     HIP_TRY(hipMemsetAsync(s->pixSum, 0, npix * sizeof(float4), st));
     HIP_TRY(hipMemsetAsync(s->pixHits, 0, npix * sizeof(int32_t), st));
+  } else {
+    std::memcpy(s->pixKey, key, sizeof key);  // an empty partition: nothing to trace, nothing for a gather to move
+    s->pixCount = 0;
   }
   if ((rc = beginEvent(s, CAT_TOTAL, timing))) return rc;
   size_t totalIdx = s->eventsUsed;
@@ -1235,7 +1292,7 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
   if (npix > 0) {
     if ((rc = beginEvent(s, CAT_RESOLVE, timing))) return rc;
     int applyExposure = (S.exposure >= 0 && !params->skipExposure) ? 1 : 0;
-    k_resolve<<<gridFor(npix), kBlock, 0, st>>>(S, (int32_t)npix, s->pixList, s->pixSum, s->pixHits, s->fb, applyExposure);
+    k_resolve<<<gridFor(npix), kBlock, 0, st>>>(S, (int32_t)npix, s->pixList, s->pixSum, s->pixHits, s->fb, s->packed, applyExposure);
     if ((rc = endEvent(s, timing))) return rc;
   }
   if (timing) HIP_TRY(hipEventRecord(s->events[totalIdx].b, st));
@@ -1278,25 +1335,68 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
 
 const float *rt_framebuffer_device(RtScene *s) { return s ? reinterpret_cast<const float *>(s->fb) : nullptr; }
 
+int rt_framebuffer_gather(RtScene *dst, RtScene *const *srcs, int32_t numSrcs) {
+  if (!dst || (numSrcs > 0 && !srcs) || numSrcs < 0) return failMsg(RT_ERR_INVALID, "null argument");
+  if (!dst->fb) return failMsg(RT_ERR_INVALID, "rt_render has not run on the destination scene");
+  const int64_t n = (int64_t)dst->dev.width * dst->dev.height;
+  for (int32_t i = 0; i < numSrcs; ++i) {
+    const RtScene *src = srcs[i];
+    if (!src || src == dst) return failMsg(RT_ERR_INVALID, "rt_framebuffer_gather needs scenes different from the destination");
+    if (!src->fb || src->pixKey[0] < 0) return failMsg(RT_ERR_INVALID, "rt_render has not run on every source scene");
+    if (n != (int64_t)src->dev.width * src->dev.height || n > dst->fbPixels || src->pixKey[0] != dst->dev.width || src->pixKey[1] != dst->dev.height)
+      return failMsg(RT_ERR_INVALID, "the framebuffers have different sizes");
+  }
+  HIP_TRY(hipSetDevice(dst->device));
+  if ((int32_t)dst->peers.size() < numSrcs) dst->peers.resize(numSrcs);
+  for (int32_t i = 0; i < numSrcs; ++i) {
+    RtScene *src = srcs[i];
+    PeerSlot &slot = dst->peers[i];
+    const int64_t npix = src->pixCount;
+    if (npix == 0) continue;
+    if (!slot.stream) HIP_TRY(hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking));
+    if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    if (slot.cap < npix) {
+      if (slot.idx) (void)hipFree(slot.idx);
+      if (slot.staging) (void)hipFree(slot.staging);
+      slot.idx = nullptr; slot.staging = nullptr; slot.cap = 0; slot.key[0] = -1;
+      HIP_TRY(hipMalloc(reinterpret_cast<void **>(&slot.idx), npix * sizeof(int32_t)));
+      HIP_TRY(hipMalloc(reinterpret_cast<void **>(&slot.staging), npix * sizeof(float4)));
+      slot.cap = npix;
+    }
+    if (std::memcmp(slot.key, src->pixKey, sizeof slot.key) != 0) {
+      // the positions of the source's pixels in the frame follow from its partition alone: rebuilt here and uploaded
+      // once per partition, so that a gather moves only the pixels themselves between the GPUs
+      RtRenderParams q{};
+      q.partIndex = src->pixKey[2]; q.partCount = src->pixKey[3]; q.tileW = src->pixKey[4]; q.tileH = src->pixKey[5];
+      std::vector<int32_t> pix = buildPixelList(q, src->pixKey[0], src->pixKey[1]);
+      if ((int64_t)pix.size() != npix) return failMsg(RT_ERR_INVALID, "source partition does not match its pixel count");
+      HIP_TRY(hipMemcpy(slot.idx, pix.data(), npix * sizeof(int32_t), hipMemcpyHostToDevice));
+      std::memcpy(slot.key, src->pixKey, sizeof slot.key);
+    }
+    if (src->device != dst->device && std::find(dst->peerEnabled.begin(), dst->peerEnabled.end(), src->device) == dst->peerEnabled.end()) {
+      hipError_t pe = hipDeviceEnablePeerAccess(src->device, 0);  // direct xGMI copies between the two GPUs
+      if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
+        (void)hipGetLastError();  // no direct path: the copy below still works, staged by the runtime
+      }
+      (void)hipGetLastError();
+      dst->peerEnabled.push_back(src->device);
+    }
+    // rt_render has synchronised both scenes' streams; each source gets a stream of its own so that the copies of
+    // different peers (different xGMI links) overlap
+    HIP_TRY(hipMemcpyPeerAsync(slot.staging, dst->device, src->packed, src->device, npix * sizeof(float4), slot.stream));
+    k_scatter_add<<<gridFor(npix), kBlock, 0, slot.stream>>>(dst->fb, slot.staging, slot.idx, npix);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(slot.done, slot.stream));
+    HIP_TRY(hipStreamWaitEvent(dst->stream, slot.done, 0));
+  }
+  HIP_TRY(hipStreamSynchronize(dst->stream));
+  return RT_OK;
+}
+
 int rt_framebuffer_add(RtScene *dst, RtScene *src) {
   if (!dst || !src || dst == src) return failMsg(RT_ERR_INVALID, "rt_framebuffer_add needs two different scenes");
-  if (!dst->fb || !src->fb) return failMsg(RT_ERR_INVALID, "rt_render has not run on both scenes");
-  int64_t n = (int64_t)dst->dev.width * dst->dev.height;
-  if (n != (int64_t)src->dev.width * src->dev.height || n > dst->fbPixels || n > src->fbPixels)
-    return failMsg(RT_ERR_INVALID, "the two framebuffers have different sizes");
-  HIP_TRY(hipSetDevice(dst->device));
-  float4 *staging = nullptr;
-  hipError_t e = hipMalloc(reinterpret_cast<void **>(&staging), n * sizeof(float4));
-  // device-to-device: over xGMI when the scenes live on different GPUs of a node (rt_render has synchronised src's stream)
-  if (e == hipSuccess) e = hipMemcpyPeerAsync(staging, dst->device, src->fb, src->device, n * sizeof(float4), dst->stream);
-  if (e == hipSuccess) {
-    k_add_frame<<<gridFor(n), kBlock, 0, dst->stream>>>(dst->fb, staging, n);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipStreamSynchronize(dst->stream);
-  if (staging) (void)hipFree(staging);
-  if (e != hipSuccess) return failMsg(RT_ERR_DEVICE, std::string("rt_framebuffer_add: ") + hipGetErrorString(e));
-  return RT_OK;
+  RtScene *one[1] = {src};
+  return rt_framebuffer_gather(dst, one, 1);
 }
 
 int rt_framebuffer_read(RtScene *s, float *rgbaOut) {
@@ -1316,15 +1416,16 @@ int rt_resolve_rgba8(RtScene *s, uint8_t *rgba8Out) {
   HIP_TRY(hipSetDevice(s->device));
   int64_t n = (int64_t)s->dev.width * s->dev.height;
   if (n > s->fbPixels) return failMsg(RT_ERR_INVALID, "framebuffer is smaller than the current image size");
-  uchar4 *d = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), n * 4));
+  int rc;
+  if ((rc = ensureWork(s, (size_t)n * 4))) return rc;
+  uchar4 *d = static_cast<uchar4 *>(s->work);
   k_srgb8<<<gridFor(n), kBlock, 0, s->stream>>>(s->fb, d, (int32_t)n);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(rgba8Out, d, n * 4, hipMemcpyDeviceToHost, s->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-  (void)hipFree(d);
-  if (e != hipSuccess) return failMsg(RT_ERR_DEVICE, std::string("rt_resolve_rgba8: ") + hipGetErrorString(e));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(rgba8Out, d, n * 4, hipMemcpyDefault, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
   return RT_OK;
 }
+
+float rt_last_trace_kernel_ms(RtScene *s) { return s ? s->lastKernelMs : 0.0f; }
 
 }  // extern "C"

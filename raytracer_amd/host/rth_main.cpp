@@ -157,10 +157,12 @@ int main(int argc, char **argv) {
       });
     }
     for (auto &w : workers) w.join();
-    for (int g = 1; g < gpus && rc[0] == RT_OK; ++g) {
-      if (rc[g] != RT_OK) continue;
-      rc[g] = rt_framebuffer_add(scenes[0], scenes[g]);
-      if (rc[g] != RT_OK) errs[g] = rt_last_error();
+    bool allOk = true;
+    for (int g = 0; g < gpus; ++g) allOk = allOk && rc[g] == RT_OK;
+    if (allOk) {
+      // one gather: every other device's own pixels (1/N of the frame each) straight to device 0, all copies in flight at once
+      int grc = rt_framebuffer_gather(scenes[0], scenes.data() + 1, gpus - 1);
+      if (grc != RT_OK) { rc[0] = grc; errs[0] = rt_last_error(); }
     }
     if (rc[0] == RT_OK) {
       rc[0] = rt_framebuffer_read(scenes[0], frame.data());

@@ -212,6 +212,15 @@ def test_device_to_device_gather_of_tile_partitions(scenes):
         parts[0].framebuffer_add(parts[2])
         got = parts[0].framebuffer_read()
         assert np.array_equal(got.reshape(whole.shape).view(np.uint32), whole.view(np.uint32))
+        # the same with one gather call, twice in a row (staging and pixel positions are kept between calls), then with
+        # a different partition on the same handles
+        for tile, seed in (((16, 16), 9), ((16, 16), 9), ((8, 32), 4)):
+            want = whole if seed == 9 else dev.render(seed=seed)[0]
+            for r, p in enumerate(parts):
+                p.render(seed=seed, part_index=r, part_count=3, tile=tile, download=False)
+            parts[0].framebuffer_gather(parts[1:])
+            got = parts[0].framebuffer_read()
+            assert np.array_equal(got.reshape(want.shape).view(np.uint32), want.view(np.uint32))
         with pytest.raises(RuntimeError, match="two different scenes"):
             parts[0].framebuffer_add(parts[0])
     finally:

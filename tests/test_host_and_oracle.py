@@ -273,8 +273,11 @@ def test_libraries_export_every_declared_symbol():
     # the oracle mirrors the same entry points under rto_
     from tests.oracle_binding import load_oracle_library
     orc = load_oracle_library()
+    # entry points about the device itself (kernel timing) have no CPU mirror
+    device_only = {"rt_last_trace_kernel_ms"}
     for sym in names:
-        assert hasattr(orc, "rto_" + sym[3:]), sym
+        if sym not in device_only:
+            assert hasattr(orc, "rto_" + sym[3:]), sym
 
 
 def test_device_library_does_not_link_the_oracle():
