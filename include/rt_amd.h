@@ -182,6 +182,16 @@ int rt_scene_set_view(RtScene *scene, const RtCamera *camera, const RtOptions *o
  * t[j] = IntersectionInfo::t (+inf on a miss). Row-major over the rectangle; host or device buffers. */
 int rt_trace_primary(RtScene *scene, int32_t x0, int32_t y0, int32_t w, int32_t h, int32_t *primId, float *t);
 
+/* rt_trace_primary for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc). It has no counterpart in the reference. Same arguments, same results bit for bit;
+ * the queue ticket and the device-side staging of ids and t live in a static device array of the library (32 MiB + 256 B
+ * per GPU, held from library load to process exit) instead of memory the scene allocates, and the call makes no
+ * hipMalloc / hipFree. Limits: w * h <= rt_trace_primary_static_max_pixels() (4 Mi pixels; larger rectangles are
+ * refused with RT_ERR_INVALID); all scenes on one GPU share that GPU's array, so calls that overlap in time on one GPU
+ * race (calls on different GPUs do not). */
+int rt_trace_primary_static(RtScene *scene, int32_t x0, int32_t y0, int32_t w, int32_t h, int32_t *primId, float *t);
+int64_t rt_trace_primary_static_max_pixels(void);
+
 /* Scene::findClosestObject (src/scene/raytracer.cpp:187-196) for n arbitrary rays.
  * origins/directions: [n*3] host floats, directions un-normalised as the reference passes them.
  * Outputs (host or device memory, any may be NULL): primId[n], t[n], point[n*3], normal[n*3]. The device-side staging of

@@ -326,6 +326,9 @@ def bind_render_abi(L, prefix):
     fn("resolve_rgba8").argtypes = [vp, C.POINTER(C.c_uint8)]
     fn("framebuffer_add").argtypes = [vp, vp]
     fn("framebuffer_gather").argtypes = [vp, C.POINTER(vp), i32]
+    if hasattr(L, prefix + "trace_primary_static"):  # HIP library only
+        fn("trace_primary_static").argtypes = [vp, i32, i32, i32, i32, C.POINTER(i32), f32p]
+        fn("trace_primary_static_max_pixels").restype = i64
     if hasattr(L, prefix + "last_trace_kernel_ms"):  # HIP library only
         fn("last_trace_kernel_ms").restype = C.c_float; fn("last_trace_kernel_ms").argtypes = [vp]
     fn("framebuffer_read").argtypes = [vp, f32p]
@@ -375,6 +378,15 @@ class RenderScene:
         ids = np.empty((h, w), dtype=np.int32)
         t = np.empty((h, w), dtype=np.float32)
         self._check(self._f("trace_primary")(self._h, x0, y0, w, h, _ip(ids), _fp(t)), "trace_primary")
+        return ids, t
+
+    def trace_primary_static(self, x0=0, y0=0, w=None, h=None):
+        """rt_trace_primary through the entry point that allocates nothing (static device scratch, bounded size)."""
+        w = self.width if w is None else w
+        h = self.height if h is None else h
+        ids = np.empty((h, w), dtype=np.int32)
+        t = np.empty((h, w), dtype=np.float32)
+        self._check(self._f("trace_primary_static")(self._h, x0, y0, w, h, _ip(ids), _fp(t)), "trace_primary_static")
         return ids, t
 
     def trace_closest(self, origins, directions):

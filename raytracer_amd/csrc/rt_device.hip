@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1007,6 +1008,35 @@ inline unsigned persistentGrid(const RtScene *s, int64_t n) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------- no-allocation entry
+// rt_trace_primary_static keeps everything it needs beyond the caller's buffers (the queue ticket and the device-side
+// staging of ids and t) in this array, which is part of the code object: every GPU the library runs on holds its own
+// copy at its own address from the moment the code object is loaded until the process ends. Host code never uses the
+// array's name as an address; it asks the runtime for the device address once per device (resolveStaticScratch).
+constexpr int64_t kStaticTraceMaxPixels = (int64_t)1 << 22;  // 4 Mi pixels (2048 x 2048): 32 MiB of staging
+constexpr size_t kStaticTicketBytes = 256;
+constexpr size_t kStaticScratchBytes = kStaticTicketBytes + (size_t)kStaticTraceMaxPixels * 8;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+void *g_scratchPtr[kMaxDevices] = {};
+std::mutex g_scratchMutex;
+
+// With `device` current: the address of this device's copy of `scratch`. Returns hipSuccess and caches the address.
+hipError_t resolveStaticScratch(int device) {
+  if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(g_scratchMutex);
+  if (g_scratchPtr[device]) return hipSuccess;
+  void *ptr = nullptr;
+  hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+  if (e != hipSuccess) return e;
+  if (!ptr) return hipErrorInvalidSymbol;
+  g_scratchPtr[device] = ptr;
+  return hipSuccess;
+}
+}  // namespace
+
 extern "C" {
 
 const char *rt_last_error(void) { return g_error.c_str(); }
@@ -1030,6 +1060,10 @@ RtScene *rt_scene_create(const RtSceneDesc *desc, int device) {
   {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_shadow<false>, kBlock, 0) == hipSuccess && nb > 0) s->blocksPerCU = nb;
+  }
+  if ((e = resolveStaticScratch(device)) != hipSuccess) {
+    g_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
+    return nullptr;
   }
   if ((e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)) != hipSuccess) {
     g_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
@@ -1130,6 +1164,31 @@ int rt_trace_primary(RtScene *s, int32_t x0, int32_t y0, int32_t w, int32_t h, i
   HIP_TRY(hipEventElapsedTime(&s->lastKernelMs, s->workEvA, s->workEvB));
   return RT_OK;
 }
+
+int rt_trace_primary_static(RtScene *s, int32_t x0, int32_t y0, int32_t w, int32_t h, int32_t *primId, float *t) {
+  if (!s || !primId || !t) return failMsg(RT_ERR_INVALID, "null argument");
+  if (w <= 0 || h <= 0) return failMsg(RT_ERR_INVALID, "empty rectangle");
+  const int64_t n = (int64_t)w * h;
+  if (n > kStaticTraceMaxPixels)
+    return failMsg(RT_ERR_INVALID, "rt_trace_primary_static: " + std::to_string(n) + " pixels exceed the static scratch buffer's " +
+                                       std::to_string(kStaticTraceMaxPixels) + "; use rt_trace_primary or a smaller rectangle");
+  HIP_TRY(hipSetDevice(s->device));
+  char *base = static_cast<char *>(s->device < kMaxDevices ? g_scratchPtr[s->device] : nullptr);  // resolved by rt_scene_create
+  if (!base) return failMsg(RT_ERR_DEVICE, "the static scratch buffer has no address on this device");
+  uint32_t *ticket = reinterpret_cast<uint32_t *>(base);
+  int32_t *dPrim = reinterpret_cast<int32_t *>(base + kStaticTicketBytes);
+  float *dT = reinterpret_cast<float *>(base + kStaticTicketBytes + (size_t)kStaticTraceMaxPixels * 4);
+  // the buffer keeps the previous call's contents: the ticket must start at zero; ids and t are fully overwritten
+  HIP_TRY(hipMemsetAsync(ticket, 0, kStaticTicketBytes, s->stream));
+  launchTracePrimary(s, x0, y0, w, h, dPrim, dT, ticket);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(primId, dPrim, n * 4, hipMemcpyDefault, s->stream));
+  HIP_TRY(hipMemcpyAsync(t, dT, n * 4, hipMemcpyDefault, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RT_OK;
+}
+
+int64_t rt_trace_primary_static_max_pixels(void) { return kStaticTraceMaxPixels; }
 
 static int traceRays(RtScene *s, bool any, int64_t n, const float *origins, const float *directions, int32_t *primId, float *t,
                      float *point, float *normal, uint8_t *occluded) {

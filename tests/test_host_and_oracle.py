@@ -273,8 +273,8 @@ def test_libraries_export_every_declared_symbol():
     # the oracle mirrors the same entry points under rto_
     from tests.oracle_binding import load_oracle_library
     orc = load_oracle_library()
-    # entry points about the device itself (kernel timing) have no CPU mirror
-    device_only = {"rt_last_trace_kernel_ms"}
+    # entry points about the device itself (kernel timing, the static-scratch variant) have no CPU mirror
+    device_only = {"rt_last_trace_kernel_ms", "rt_trace_primary_static", "rt_trace_primary_static_max_pixels"}
     for sym in names:
         if sym not in device_only:
             assert hasattr(orc, "rto_" + sym[3:]), sym
