@@ -8,7 +8,7 @@ HIPCC   ?= /opt/rocm/bin/hipcc
 CXX     ?= g++
 # No fused multiply-add anywhere a hit decision is made: the reference's x86-64 build has none.
 HOSTFLAGS := -std=c++17 -O2 -fPIC -ffp-contract=off -Wall -Wextra -Wno-unused-parameter -I$(ROOT)include -I$(HOSTDIR)
-HIPFLAGS  := -std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -I$(ROOT)include -I$(CSRC) \
+HIPFLAGS  := -std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize $(HIPEXTRA) -I$(ROOT)include -I$(CSRC) \
              -Wall -Wno-unused-parameter
 
 HOST_SRCS := $(HOSTDIR)/rth_scene.cpp $(HOSTDIR)/rth_bvh.cpp $(HOSTDIR)/rth_parse.cpp $(HOSTDIR)/rth_png.cpp $(HOSTDIR)/rth_capi.cpp

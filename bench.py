@@ -280,7 +280,11 @@ def main():
         "wall_time_s": round(ms_per_step / 1e3, 3),
         "camera_msamples_per_s": round(samples_total / elapsed / 1e6, 2),
         "rays_per_frame": int(rays_total / args.steps),
+        # visibility queries the reference traces and this library answers without a traversal (zero contribution, or a
+        # plane alone decides); `value` counts traversed queries only
         "rays_skipped_per_frame": int(sum(s.raysSkipped for s in stats) / args.steps),
+        "rays_plane_answered_per_frame": int(sum(s.raysPlaneAnswered for s in stats) / args.steps),
+        "reference_queries_per_frame": int((rays_total + sum(s.raysSkipped for s in stats)) / args.steps) if world == 1 else None,
         "rays_per_camera_sample": round(rays_total / max(1.0, samples_total), 3),
         "kernel_ms_per_frame": {k: round(sum(getattr(s, k) for s in stats) / args.steps, 2)
                                 for k in ("msTotal", "msRaygen", "msExtend", "msShade", "msShadow", "msDirect", "msAccumulate", "msResolve")},

@@ -158,10 +158,12 @@ typedef struct RtStats {
   /* only with collectCounters: average fraction of a wavefront's 64 lanes that do work in the inner-node loop and in
    * the primitive-test loop, per traversal kernel (1.0 = no divergence loss) */
   double laneUseInnerExtend, laneUsePrimExtend, laneUseInnerShadow, laneUsePrimShadow;
-  /* light-visibility queries the reference traces (src/scene/raytracer.cpp:198-206) but the HIP library does not,
-   * because the light's unshadowed contribution was already exactly zero; not included in raysClosest / raysAny /
-   * raysShadow, which count traced queries only */
+  /* light-visibility queries the reference traces (src/scene/raytracer.cpp:198-206) but the HIP library answers
+   * without touching the BVH: the light's unshadowed contribution was already exactly zero, or (raysPlaneAnswered, a
+   * subset) one of the scene's planes alone decides the yes/no answer; not included in raysClosest / raysAny /
+   * raysShadow, which count traversed queries only */
   uint64_t raysSkipped;
+  uint64_t raysPlaneAnswered;
 } RtStats;
 
 typedef struct RtScene RtScene;

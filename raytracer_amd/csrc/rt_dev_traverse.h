@@ -38,6 +38,7 @@ RT_DEV float intersectAABB(V3 o, V3 inv, float mnx, float mny, float mnz, float 
 }
 
 struct TravCounters {
+  uint32_t planeAnsweredPoint, planeAnsweredAny;  // always counted: visibility queries the planes answered (no BVH traversal)
   uint32_t inner, prims, planes;
   // wave-level iteration counts (each active lane adds 1/active, so the wave sums to 1 per iteration): with `inner`
   // and `prims` they give the fraction of the 64 lanes doing useful work in the two hot loops
@@ -97,13 +98,16 @@ RT_DEV float intersectAABBFinite(V3 o, V3 inv, float mnx, float mny, float mnz, 
 #ifndef RT_CHUNK_DIV
 #define RT_CHUNK_DIV 16
 #endif
-constexpr uint32_t kTicketChunkMax = RT_CHUNK_MAX, kTicketChunkMin = 64, kChunksPerWave = RT_CHUNK_DIV;  // a refill takes up to 64 indices: a chunk must cover one
+constexpr uint32_t kTicketChunkMax = RT_CHUNK_MAX, kTicketChunkMin = 64, kChunksPerWave = RT_CHUNK_DIV;  // a prepare step takes up to 64 indices: a chunk must cover one
 
 enum { TRAV_CLOSEST = 0, TRAV_ANY = 1, TRAV_POINT_LIGHT = 2, TRAV_SKIP = 3 };
 
 // Scheduling thresholds of the traversal engine (lanes of one 64-lane wavefront).
-#ifndef RT_SERVICE_MIN
-#define RT_SERVICE_MIN 24
+#ifndef RT_POOL_SLOTS
+#define RT_POOL_SLOTS 32
+#endif
+#ifndef RT_POOL_LOW
+#define RT_POOL_LOW (RT_POOL_SLOTS / 4)
 #endif
 #ifndef RT_STAY_INNER
 #define RT_STAY_INNER 3
@@ -111,7 +115,17 @@ enum { TRAV_CLOSEST = 0, TRAV_ANY = 1, TRAV_POINT_LIGHT = 2, TRAV_SKIP = 3 };
 #ifndef RT_STAY_PRIM
 #define RT_STAY_PRIM 1
 #endif
-constexpr int kServiceMin = RT_SERVICE_MIN;  // lanes without work (finished or idle) before results are written and the queue is visited
+#ifndef RT_DONE_BREAK
+#define RT_DONE_BREAK 12
+#endif
+#ifndef RT_TAKE_MIN
+#define RT_TAKE_MIN 8
+#endif
+constexpr int kPoolSlots = RT_POOL_SLOTS;    // prepared queries a wavefront keeps in LDS (power of two)
+constexpr int kPoolFields = 13;   // dwords per prepared query
+constexpr int kPoolLow = RT_POOL_LOW;      // prepare more queries once at most this many are left
+constexpr int kDoneBreak = RT_DONE_BREAK;  // a phase loop ends early once this many lanes have finished their query
+constexpr int kTakeMin = RT_TAKE_MIN;      // lanes without work (done or idle) before results are written and new queries taken
 
 // Limits the host checks before a scene reaches the GPU (rt_scene_create): node and object records are addressed
 // with 32-bit byte offsets, and the per-lane stack has the reference's 64 entries (src/acceleration/BVH.cpp:10), which
@@ -124,16 +138,20 @@ constexpr int kMaxTreeDepth = kMaxStack;
 // query per lane. Each lane always has exactly one pending operation:
 //     INNER   test the two child boxes of an inner node, descend / push / pop
 //     PRIM    test one object of the current leaf
-//     FINISH  planes + result write-out of a query whose BVH part is over
+//     DONE    the BVH part of its query is over: the result has to be written out
 //     IDLE    no query
-// The wavefront votes: once kServiceMin lanes have no work (their query is finished, or they never had one) a service
-// step writes the finished results out and gives every such lane a new query from the queue; otherwise the more
-// popular of INNER / PRIM runs in a tight loop of its own until too few of its lanes are left, while the minority
-// waits until it has become the majority. Incoherent
-// rays therefore do not serialise the wavefront through both loop bodies every iteration, and a few long traversals
-// do not leave most lanes waiting: finished queries are REPLACED by new ones. Per query, nodes and objects are still
-// visited in exactly the reference's order. The grid is sized to fill the GPU once (persistent wavefronts); a wavefront ends when the
-// queue is exhausted and its own lanes are done, so nothing ever waits on another wavefront.
+// A wavefront keeps a small pool of PREPARED queries in LDS. Preparing is the expensive start of a query (load it,
+// normalise the direction, three IEEE divisions, the planes, the root box) and runs for up to kPoolSlots queries at
+// once, on all lanes, whatever their own query is doing meanwhile: their registers are not touched. A query that is
+// decided at this point (a plane answers it, it misses the root box, its answer cannot matter) is written out at once
+// and never occupies a lane. At every vote, lanes in DONE write their result (a few instructions) and lanes without a
+// query take the next prepared one from the pool (14 LDS reads), so a lane is idle only until the current phase loop
+// ends, not until two dozen others have finished too.
+// The wavefront then votes: the more popular of INNER / PRIM runs in a tight loop of its own until too few of its lanes
+// are left (or too many lanes are done), while the minority waits until it has become the majority. Incoherent rays
+// therefore do not serialise the wavefront through both loop bodies every iteration. Per query, nodes and objects are
+// visited in exactly the reference's order. The grid is sized to fill the GPU once (persistent wavefronts); a wavefront
+// ends when the queue is exhausted, its pool is empty and its own lanes are done, so nothing ever waits on another wavefront.
 //
 // Query kinds:
 //   TRAV_CLOSEST      Scene::findClosestObject (src/scene/raytracer.cpp:187-196)
@@ -150,20 +168,26 @@ constexpr int kMaxTreeDepth = kMaxStack;
 //   uint32_t total()                                                       number of queries in the queue
 //   uint32_t fetch(uint32_t idx, V3 &o, V3 &d, int &mode, float &bulbDist) load query idx, return a tag for store()
 //   void store(uint32_t tag, HitRec hit, bool occluded, V3 o, V3 nd)       deliver its result
+//
+// LDS the caller provides: ldsStack = K * BLOCK uint2 (stack columns), ldsPool = (BLOCK / 64) * kPoolFields * kPoolSlots dwords.
 template <class Source, bool RUNTIME_MODE, bool COUNT, int K, int BLOCK>
-RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint2 *ldsStack, TravCounters &tc) {
+RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint2 *ldsStack, uint32_t *ldsPool, TravCounters &tc) {
   static_assert((K & (K - 1)) == 0, "K must be a power of two");
+  static_assert((kPoolSlots & (kPoolSlots - 1)) == 0 && kPoolSlots <= 64, "pool size");
   const uint32_t total = src.total();
   const uint32_t laneId = __lane_id();
   const char *nodeBase = reinterpret_cast<const char *>(S.nodes);
   const char *primBase = reinterpret_cast<const char *>(S.primHit);
   uint2 *stackCol = ldsStack + threadIdx.x;
+  uint32_t *pool = ldsPool + (threadIdx.x >> 6) * (kPoolFields * kPoolSlots);  // [field][slot]
   uint2 spill[kMaxStack - K];
-  enum { OP_IDLE = 0, OP_INNER = 1, OP_PRIM = 2, OP_FINISH = 3, OP_FINISH_EARLY = 4 };
+  enum { OP_IDLE = 0, OP_INNER = 1, OP_PRIM = 2, OP_DONE = 3, OP_DONE_EARLY = 4 };
   int op = OP_IDLE;
   uint32_t item = 0;
   V3 o = v3(0, 0, 0), nd = o, inv = o;
   float tBest = kInf, bulbDist = 0.0f;
+  float tPlane = kInf;     // closest plane along the ray (found when the query was prepared)
+  int32_t planeBest = -1;
   float cullD = kInf;  // TRAV_POINT_LIGHT: boxes entered beyond this distance (in units of |d|) cannot matter, see below
   int32_t primBest = -1, cur = 0, pi = 0, pe = 0;
   int sp = 0, lo = 0, mode = TRAV_CLOSEST;
@@ -171,6 +195,7 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
   bool exhausted = false;  // wave-uniform: the queue has no more queries
   bool waveExact = false;  // wave-uniform: some lane holds a ray the min/max slab test is not valid for
   uint32_t chunkPos = 0, chunkEnd = 0;
+  uint32_t poolHead = 0, poolCount = 0;  // wave-uniform ring of prepared queries
   const uint32_t kTicketChunk = min(kTicketChunkMax, max(kTicketChunkMin, total / (gridDim.x * (BLOCK / 64) * kChunksPerWave)));
 
   // an inner node becomes an INNER operation, a leaf a run of PRIM operations
@@ -191,7 +216,7 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
   // next stack entry whose box entry distance is still below the closest hit (src/acceleration/BVH.cpp:302-305);
   // none left: the BVH part of the query is over
   auto popNext = [&]() {
-    op = OP_FINISH;
+    op = OP_DONE;
     while (sp > 0) {
       --sp;
       // A spilled entry is first copied back into its LDS slot (rare), so that the read below is always a plain LDS
@@ -203,103 +228,165 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
       if (__uint_as_float(e.x) < (RUNTIME_MODE ? __builtin_fminf(tBest, cullD) : tBest)) { enter((int32_t)e.y); break; }
     }
   };
+  // The end of a query. The closest plane was found when the query was prepared; the reference tests the planes after
+  // the BVH and lets a plane win only on a strict `<` (src/scene/raytracer.cpp:190-195), which is this comparison.
+  // Visibility queries: a plane that answers the question alone ended the query before it reached a lane, and object
+  // hits of a point-light query were checked when they were accepted, so only TRAV_ANY is left to decide here.
+  auto deliver = [&](uint32_t tag, bool early, int qmode, float tB, int32_t pB, float tP, int32_t plane, V3 qo, V3 qnd) {
+    bool occluded = early;
+    if (!early) {
+      if (plane >= 0 && tP < tB) { tB = tP; pB = S.numPrims + plane; }
+      if (!(RUNTIME_MODE && qmode == TRAV_POINT_LIGHT)) occluded = pB >= 0;
+    }
+    HitRec h;
+    h.t = pB >= 0 ? tB : kInf;
+    h.prim = pB;
+    src.store(tag, h, occluded, qo, qnd);
+  };
 
   while (true) {
-    const unsigned long long mInner = __ballot(op == OP_INNER), mPrim = __ballot(op == OP_PRIM);
-    const int nInner = __popcll(mInner), nPrim = __popcll(mPrim);
-    const int nOther = 64 - nInner - nPrim;  // finished + idle lanes
-    if (nOther >= kServiceMin || nInner + nPrim == 0) {
-      const unsigned long long mFinish = __ballot(op >= OP_FINISH);
-      const int nFinish = __popcll(mFinish), nIdle = nOther - nFinish;
-      // one special step serves both: finished queries are written out and, in the same step, every idle lane
-      // (the ones just finished included) takes a new query
-      const bool doFinish = nFinish > 0, doRefill = !exhausted && nIdle + nFinish > 0;
-      if (doFinish) {
-        // -------------------------------------------------------------- FINISH: planes, result, lane becomes idle
-        if (op >= OP_FINISH) {
-          bool occluded = op == OP_FINISH_EARLY;
-          if (op == OP_FINISH) {
-            for (int32_t k = 0; k < S.numPlanes; ++k) {
-              // Plane::intersect, src/scene/Object.cpp:133-141; planes lose ties to BVH objects (raytracer.cpp:192)
-              if (COUNT) ++tc.planes;
-              const DevPlane &pl = S.planes[k];
-              V3 pn = v3(pl.normal), pp = v3(pl.point);
-              float t = dot(pp - o, pn) / dot(nd, pn);
-              if (t < 0) continue;
-              if (t < tBest) {
-                tBest = t; primBest = S.numPrims + k;
-                if (RUNTIME_MODE && mode == TRAV_ANY) break;
-              }
-            }
-            if (RUNTIME_MODE && mode == TRAV_POINT_LIGHT) {
-              // object hits were checked when they were accepted; only a plane can still satisfy the predicate
-              if (primBest >= S.numPrims) {
-                V3 hp = tBest * nd + o;
-                occluded = magnitude(o - hp) < bulbDist;
-              }
-            } else {
-              occluded = primBest >= 0;
-            }
-          }
-          HitRec h;
-          h.t = primBest >= 0 ? tBest : kInf;
-          h.prim = primBest;
-          src.store(item, h, occluded, o, nd);
-          op = OP_IDLE;
-          finite = true;
-        }
+    const int nWorking = __popcll(__ballot(op == OP_INNER || op == OP_PRIM));
+    const bool service = 64 - nWorking >= kTakeMin || nWorking == 0;
+    // ------------------------------------------------------------------ DONE lanes write their result and become idle
+    if (service && __ballot(op >= OP_DONE) != 0ull) {
+      if (op >= OP_DONE) {
+        deliver(item, op == OP_DONE_EARLY, mode, tBest, primBest, tPlane, planeBest, o, nd);
+        op = OP_IDLE;
+        finite = true;
       }
-      if (doRefill) {
-        // -------------------------------------------------------------- REFILL idle lanes from the queue
-        const unsigned long long mIdle = __ballot(op == OP_IDLE);
-        int leader = __ffsll((long long)mIdle) - 1;
+    }
+    // ------------------------------------------------------------------ PREPARE queries into the pool
+    // Runs on lanes 0 .. n-1 whatever their own state: only the variables declared inside are written.
+    if (service && !exhausted && poolCount <= (uint32_t)kPoolLow) {
+      const uint32_t want = (uint32_t)kPoolSlots - poolCount;  // <= 64
+      const uint32_t avail = chunkEnd - chunkPos;
+      uint32_t idx = chunkPos + laneId;
+      if (avail < want) {
         // Queue indices come from a wave-local chunk [chunkPos, chunkEnd); one atomic on the shared counter buys
         // kTicketChunk of them, so the counter (a single address all wavefronts hit) sees few operations.
-        const uint32_t avail = chunkEnd - chunkPos, want = (uint32_t)__popcll(mIdle);
-        const uint32_t rank = (uint32_t)__popcll(mIdle & ((1ull << laneId) - 1ull));
-        uint32_t idx = chunkPos + rank;
-        if (avail < want) {
-          uint32_t base = 0;
-          if ((int)laneId == leader) base = atomicAdd(ticket, kTicketChunk);
-          base = __shfl(base, leader);
-          if (rank >= avail) idx = base + (rank - avail);
-          chunkPos = base + (want - avail);
-          chunkEnd = base + kTicketChunk;
-          if (base >= total) { exhausted = true; chunkPos = chunkEnd = 0; }
-        } else {
-          chunkPos += want;
-        }
-        if (op == OP_IDLE && idx < total) {
-          V3 d;
-          item = src.fetch(idx, o, d, mode, bulbDist);
-          nd = normalized(d);
-          tBest = kInf; primBest = -1; sp = 0; lo = 0;
-          const bool skip = RUNTIME_MODE && mode == TRAV_SKIP;
-          op = skip ? OP_IDLE : OP_FINISH;
-          // A point-light query only asks whether the closest hit lies nearer than the bulb. With |d| = bulbDist >= 1
-          // the reference's culling is conservative (box distances are in units of |d|, t in units of 1, so a box is
-          // never farther than its distance says) and its closest hit is the true one; every object in a box entered
-          // beyond the bulb (distance > 1 in units of |d|, plus a 1 % margin for rounding) is hit beyond the bulb, which
-          // answers the question like no hit at all. Such boxes are skipped. For bulbDist < 1 the reference's culling
-          // can drop nearer hits depending on what it visited before, so nothing is skipped then.
-          cullD = (RUNTIME_MODE && mode == TRAV_POINT_LIGHT && bulbDist >= 1.0f) ? 1.01f : kInf;
-          if (S.rootRef != kNoBvh && !skip) {
-            inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // src/acceleration/BVH.cpp:293
-            finite = S.boxesFinite && isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z) && inv.x != 0 && inv.y != 0 &&
-                     inv.z != 0 && isfinite(o.x) && isfinite(o.y) && isfinite(o.z);
-            float rootDist = intersectAABB(o, inv, S.rootMin[0], S.rootMin[1], S.rootMin[2], S.rootMax[0], S.rootMax[1], S.rootMax[2]);
-            if (rootDist < cullD) enter(S.rootRef);
+        uint32_t base = 0;
+        if (laneId == 0) base = atomicAdd(ticket, kTicketChunk);
+        base = __shfl(base, 0);
+        if (laneId >= avail) idx = base + (laneId - avail);
+        chunkPos = base + (want - avail);
+        chunkEnd = base + kTicketChunk;
+        if (base >= total) { exhausted = true; chunkPos = chunkEnd = 0; }
+      } else {
+        chunkPos += want;
+      }
+      bool pooled = false;
+      V3 qo = v3(0, 0, 0), qnd = qo, qinv = qo;
+      float qtPlane = kInf, qbulb = 0.0f;
+      int32_t qplane = -1, qfirst = kNoBvh;
+      int qmode = TRAV_CLOSEST;
+      bool qfinite = true;
+      uint32_t qitem = 0;
+      if (laneId < want && idx < total) {
+        V3 d;
+        qitem = src.fetch(idx, qo, d, qmode, qbulb);
+        if (!(RUNTIME_MODE && qmode == TRAV_SKIP)) {
+          qnd = normalized(d);
+          // Planes first. The reference tests them after the BVH (src/scene/raytracer.cpp:174-196), each with
+          // Plane::intersect (src/scene/Object.cpp:133-141), keeping the first plane in scene order that reaches the
+          // smallest t; that plane does not depend on the BVH part, so it is found here and compared at the end.
+          // A visibility query asks a yes/no question that a plane alone can settle: findAnyObject is non-null as soon
+          // as any plane is hit (:177-183), and a point-light query is in shadow as soon as a plane lies nearer than
+          // the bulb (the closest hit overall is then nearer still; src/scene/Object.cpp:18-25). Such a query needs no
+          // traversal at all; it is counted apart (TravCounters::planeAnswered*).
+          for (int32_t k = 0; k < S.numPlanes; ++k) {
+            if (COUNT) ++tc.planes;
+            const DevPlane &pl = S.planes[k];
+            V3 pn = v3(pl.normal), pp = v3(pl.point);
+            float t = dot(pp - qo, pn) / dot(qnd, pn);
+            if (t < 0) continue;
+            if (t < qtPlane) { qtPlane = t; qplane = k; }
+          }
+          bool planeAnswers = false;
+          if (RUNTIME_MODE && qplane >= 0) {
+            if (qmode == TRAV_ANY) {
+              planeAnswers = true; ++tc.planeAnsweredAny;
+            } else if (qmode == TRAV_POINT_LIGHT) {
+              V3 hp = qtPlane * qnd + qo;
+              if (magnitude(qo - hp) < qbulb) { planeAnswers = true; ++tc.planeAnsweredPoint; }
+            }
+          }
+          if (planeAnswers) {
+            deliver(qitem, true, qmode, qtPlane, S.numPrims + qplane, qtPlane, qplane, qo, qnd);
+          } else {
+            // A point-light query only asks whether the closest hit lies nearer than the bulb. With |d| = bulbDist >= 1
+            // the reference's culling is conservative (box distances are in units of |d|, t in units of 1, so a box is
+            // never farther than its distance says) and its closest hit is the true one; every object in a box entered
+            // beyond the bulb (distance > 1 in units of |d|, plus a 1 % margin for rounding) is hit beyond the bulb, which
+            // answers the question like no hit at all. Such boxes are skipped. For bulbDist < 1 the reference's culling
+            // can drop nearer hits depending on what it visited before, so nothing is skipped then.
+            const float qcull = (RUNTIME_MODE && qmode == TRAV_POINT_LIGHT && qbulb >= 1.0f) ? 1.01f : kInf;
+            if (S.rootRef != kNoBvh) {
+              qinv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // src/acceleration/BVH.cpp:293
+              qfinite = S.boxesFinite && isfinite(qinv.x) && isfinite(qinv.y) && isfinite(qinv.z) && qinv.x != 0 && qinv.y != 0 &&
+                        qinv.z != 0 && isfinite(qo.x) && isfinite(qo.y) && isfinite(qo.z);
+              float rootDist = intersectAABB(qo, qinv, S.rootMin[0], S.rootMin[1], S.rootMin[2], S.rootMax[0], S.rootMax[1], S.rootMax[2]);
+              if (rootDist < qcull) qfirst = S.rootRef;
+            }
+            if (qfirst == kNoBvh) deliver(qitem, false, qmode, kInf, -1, qtPlane, qplane, qo, qnd);  // nothing to traverse
+            else pooled = true;
           }
         }
-        waveExact = __ballot(!finite) != 0ull;
-        continue;
       }
-      if (doFinish) { waveExact = __ballot(!finite) != 0ull; continue; }
-      if (nInner + nPrim == 0) break;  // every lane idle and the queue exhausted
+      const unsigned long long mPooled = __ballot(pooled);
+      if (pooled) {
+        const uint32_t e = (poolHead + poolCount + (uint32_t)__popcll(mPooled & ((1ull << laneId) - 1ull))) & (kPoolSlots - 1);
+        uint32_t *q = pool + e;
+        q[0 * kPoolSlots] = __float_as_uint(qo.x); q[1 * kPoolSlots] = __float_as_uint(qo.y); q[2 * kPoolSlots] = __float_as_uint(qo.z);
+        q[3 * kPoolSlots] = __float_as_uint(qnd.x); q[4 * kPoolSlots] = __float_as_uint(qnd.y); q[5 * kPoolSlots] = __float_as_uint(qnd.z);
+        q[6 * kPoolSlots] = __float_as_uint(qinv.x); q[7 * kPoolSlots] = __float_as_uint(qinv.y); q[8 * kPoolSlots] = __float_as_uint(qinv.z);
+        // A visibility query that reaches the pool has no use for the planes any more (a plane that could answer it
+        // has answered it above), so its bulb distance travels in the closest-plane slot.
+        q[9 * kPoolSlots] = __float_as_uint(RUNTIME_MODE ? qbulb : qtPlane);
+        q[10 * kPoolSlots] = qitem;
+        q[11 * kPoolSlots] = (uint32_t)qfirst;
+        q[12 * kPoolSlots] = (uint32_t)(qplane + 1) | ((uint32_t)qmode << 16) | ((uint32_t)qfinite << 20);
+      }
+      poolCount += (uint32_t)__popcll(mPooled);
+    }
+    // ------------------------------------------------------------------ idle lanes TAKE prepared queries
+    if (service) {
+      const unsigned long long mIdle = __ballot(op == OP_IDLE);
+      if (mIdle != 0ull && poolCount > 0) {
+        const uint32_t rank = (uint32_t)__popcll(mIdle & ((1ull << laneId) - 1ull));
+        if (op == OP_IDLE && rank < poolCount) {
+          const uint32_t *q = pool + ((poolHead + rank) & (kPoolSlots - 1));
+          o = v3(__uint_as_float(q[0 * kPoolSlots]), __uint_as_float(q[1 * kPoolSlots]), __uint_as_float(q[2 * kPoolSlots]));
+          nd = v3(__uint_as_float(q[3 * kPoolSlots]), __uint_as_float(q[4 * kPoolSlots]), __uint_as_float(q[5 * kPoolSlots]));
+          inv = v3(__uint_as_float(q[6 * kPoolSlots]), __uint_as_float(q[7 * kPoolSlots]), __uint_as_float(q[8 * kPoolSlots]));
+          if (RUNTIME_MODE) { bulbDist = __uint_as_float(q[9 * kPoolSlots]); tPlane = kInf; }
+          else tPlane = __uint_as_float(q[9 * kPoolSlots]);
+          item = q[10 * kPoolSlots];
+          const int32_t first = (int32_t)q[11 * kPoolSlots];
+          const uint32_t packed = q[12 * kPoolSlots];
+          planeBest = RUNTIME_MODE ? -1 : (int32_t)(packed & 0xffffu) - 1;
+          mode = (int)((packed >> 16) & 0xfu);
+          finite = ((packed >> 20) & 1u) != 0u;
+          if (RUNTIME_MODE) cullD = (mode == TRAV_POINT_LIGHT && bulbDist >= 1.0f) ? 1.01f : kInf;
+          tBest = kInf; primBest = -1; sp = 0; lo = 0;
+          enter(first);
+        }
+        const uint32_t taken = min((uint32_t)__popcll(mIdle), poolCount);
+        poolHead = (poolHead + taken) & (kPoolSlots - 1);
+        poolCount -= taken;
+        waveExact = __ballot(!finite) != 0ull;
+        if (!exhausted && poolCount <= (uint32_t)kPoolLow && __ballot(op == OP_IDLE) != 0ull) continue;  // lanes still idle: prepare more at once
+      }
+    }
+    const unsigned long long mInner = __ballot(op == OP_INNER), mPrim = __ballot(op == OP_PRIM);
+    const int nInner = __popcll(mInner), nPrim = __popcll(mPrim);
+    if (nInner + nPrim == 0) {
+      if (exhausted && poolCount == 0) break;  // every lane idle, nothing prepared, nothing left in the queue
+      continue;
     }
     // a phase ends once its lanes have fallen to 3/8 (INNER) or 1/8 (PRIM) of the lanes that had work at the vote:
     // measured best on MI355X (a PRIM phase is short, so running it almost dry costs little and saves votes)
     const int stayInner = ((nInner + nPrim) * RT_STAY_INNER) >> 3, stayPrim = ((nInner + nPrim) * RT_STAY_PRIM) >> 3;
+    const bool canRefill = poolCount > 0 || !exhausted;  // a finished lane can be given a new query at the next vote
     if (nInner >= nPrim) {
       // ---------------------------------------------------------------- INNER: both child boxes of the current node
       int n = nInner;
@@ -332,6 +419,7 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
           else popNext();
         }
         n = __popcll(__ballot(op == OP_INNER));
+        if (canRefill && __popcll(__ballot(op >= OP_DONE)) >= kDoneBreak) break;
       } while (n > stayInner);
     } else {
       // ---------------------------------------------------------------- PRIM: one object of the current leaf
@@ -344,11 +432,11 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
           ++pi;
           if (RUNTIME_MODE && accepted && mode != TRAV_CLOSEST) {
             if (mode == TRAV_ANY) {
-              op = OP_FINISH_EARLY;
+              op = OP_DONE_EARLY;
             } else {
               // |point - info.point| < |center - point| with info.point = t * nd + origin (src/scene/Object.cpp:22-24)
               V3 hp = tBest * nd + o;
-              if (magnitude(o - hp) < bulbDist) op = OP_FINISH_EARLY;
+              if (magnitude(o - hp) < bulbDist) op = OP_DONE_EARLY;
             }
           }
           if (op == OP_PRIM && pi == pe) popNext();

@@ -35,6 +35,15 @@ using namespace rtd;
 namespace {
 
 constexpr int kBlock = 256;       // 4 wavefronts
+// Register budget of the traversal kernels: waves per SIMD the compiler must leave room for, and the scalar-register cap
+// that goes with it (256-thread blocks are admitted per CU by 800 / (sgprs rounded up to 16, + 16)).
+#ifndef RT_TRAV_WAVES
+#define RT_TRAV_WAVES 7
+#endif
+#ifndef RT_TRAV_SGPRS
+#define RT_TRAV_SGPRS 96
+#endif
+#define RT_TRAV_ATTR __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_TRAV_WAVES, 8), amdgpu_num_sgpr(RT_TRAV_SGPRS)))
 constexpr int kStackLds = 8;      // stack entries per lane kept in LDS (8 B each -> 16 KiB per block)
 
 // Every group of fields that one kernel updates with atomics while others only read sits in a 128-byte line of its own:
@@ -49,6 +58,7 @@ struct Counts {
   Ticket ticket[3];               // [0] path extension, [1] light visibility, [2] trace-only kernels
   alignas(128) unsigned long long skipPoint;  // visibility queries not traced (see ShadowSource), by query kind
   unsigned long long skipAny;
+  unsigned long long planePoint, planeAny;    // visibility queries a plane answered before any BVH node was touched
   alignas(128) unsigned long long raysClosest, raysAny, samples, raysExtend, raysShadow;
   unsigned long long inner[2], prims[2], planes[2];  // [0] path extension, [1] light visibility
   float innerWaveIters[2], primWaveIters[2];
@@ -192,11 +202,13 @@ struct ExtendSource {
 };
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_extend(DevScene S, PathBuf B, const uint32_t *queue) {
+__global__ RT_TRAV_ATTR void k_extend(DevScene S, PathBuf B, const uint32_t *queue) {
   __shared__ uint2 ldsStack[kStackLds * kBlock];
-  TravCounters tc = {0, 0, 0, 0.0f, 0.0f};
+
+  __shared__ uint32_t ldsPool[(kBlock / 64) * kPoolFields * kPoolSlots];
+  TravCounters tc = {0, 0, 0, 0, 0, 0.0f, 0.0f};
   ExtendSource src{B, queue};
-  traverseQueue<ExtendSource, false, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[0].next, ldsStack, tc);
+  traverseQueue<ExtendSource, false, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[0].next, ldsStack, ldsPool, tc);
   flushCounters<COUNT>(B.counts, tc, 0);
 }
 
@@ -368,17 +380,22 @@ struct ShadowSource {
 };
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_shadow(DevScene S, PathBuf B) {
+__global__ RT_TRAV_ATTR void k_shadow(DevScene S, PathBuf B) {
   __shared__ uint2 ldsStack[kStackLds * kBlock];
-  TravCounters tc = {0, 0, 0, 0.0f, 0.0f};
+  __shared__ uint32_t ldsPool[(kBlock / 64) * kPoolFields * kPoolSlots];
+  TravCounters tc = {0, 0, 0, 0, 0, 0.0f, 0.0f};
   ShadowSource src{S, B, B.counts->nHit};
-  traverseQueue<ShadowSource, true, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[1].next, ldsStack, tc);
+  traverseQueue<ShadowSource, true, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[1].next, ldsStack, ldsPool, tc);
   flushCounters<COUNT>(B.counts, tc, 1);
-  uint32_t sp = src.skippedPoint, sa = src.skippedAny;
-  for (int off = 32; off > 0; off >>= 1) { sp += __shfl_down(sp, off); sa += __shfl_down(sa, off); }
-  if (__lane_id() == 0) {  // one wavefront = up to two atomics per launch, on a line of their own
+  uint32_t sp = src.skippedPoint, sa = src.skippedAny, pp = tc.planeAnsweredPoint, pa = tc.planeAnsweredAny;
+  for (int off = 32; off > 0; off >>= 1) {
+    sp += __shfl_down(sp, off); sa += __shfl_down(sa, off); pp += __shfl_down(pp, off); pa += __shfl_down(pa, off);
+  }
+  if (__lane_id() == 0) {  // one wavefront = up to four atomics per launch, on a line of their own
     if (sp) atomicAdd(&B.counts->skipPoint, (unsigned long long)sp);
     if (sa) atomicAdd(&B.counts->skipAny, (unsigned long long)sa);
+    if (pp) atomicAdd(&B.counts->planePoint, (unsigned long long)pp);
+    if (pa) atomicAdd(&B.counts->planeAny, (unsigned long long)pa);
   }
 }
 
@@ -521,9 +538,10 @@ struct PrimarySource {
 __global__ __launch_bounds__(kBlock) void k_trace_primary(DevScene S, int32_t x0, int32_t y0, int32_t w, int32_t h,
                                                           int32_t *outPrim, float *outT, uint32_t *ticket) {
   __shared__ uint2 ldsStack[kStackLds * kBlock];
-  TravCounters tc = {0, 0, 0, 0.0f, 0.0f};
+  __shared__ uint32_t ldsPool[(kBlock / 64) * kPoolFields * kPoolSlots];
+  TravCounters tc = {0, 0, 0, 0, 0, 0.0f, 0.0f};
   PrimarySource src{S, x0, y0, w, h, outPrim, outT};
-  traverseQueue<PrimarySource, false, false, kStackLds, kBlock>(S, src, ticket, ldsStack, tc);
+  traverseQueue<PrimarySource, false, false, kStackLds, kBlock>(S, src, ticket, ldsStack, ldsPool, tc);
 }
 
 template <bool ANY>
@@ -574,9 +592,10 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene S, int64_t n, co
                                                        int32_t *outPrim, float *outT, float *outPoint, float *outNormal,
                                                        uint8_t *outOccluded, uint32_t *ticket) {
   __shared__ uint2 ldsStack[kStackLds * kBlock];
-  TravCounters tc = {0, 0, 0, 0.0f, 0.0f};
+  __shared__ uint32_t ldsPool[(kBlock / 64) * kPoolFields * kPoolSlots];
+  TravCounters tc = {0, 0, 0, 0, 0, 0.0f, 0.0f};
   RaysSource<ANY> src{S, n, origins, directions, outPrim, outT, outPoint, outNormal, outOccluded};
-  traverseQueue<RaysSource<ANY>, ANY, false, kStackLds, kBlock>(S, src, ticket, ldsStack, tc);
+  traverseQueue<RaysSource<ANY>, ANY, false, kStackLds, kBlock>(S, src, ticket, ldsStack, ldsPool, tc);
 }
 
 // ---------------------------------------------------------------------------------------------------- host side
@@ -618,6 +637,7 @@ struct RtScene {
   int32_t numPointLights = 0, numAnyLights = 0, numEnvLights = 0;
   int numCUs = 256;
   int blocksPerCU = 4;  // resident blocks of a traversal kernel per CU (occupancy query at scene creation)
+  size_t extraLds = 0;  // RT_TRAV_EXTRA_LDS: unused dynamic LDS per traversal block, to lower occupancy in experiments
   // render state (allocated on first use, grown when needed)
   PathBuf buf{};
   void *arena = nullptr;
@@ -1059,7 +1079,9 @@ RtScene *rt_scene_create(const RtSceneDesc *desc, int device) {
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->numCUs = prop.multiProcessorCount;
   {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_shadow<false>, kBlock, 0) == hipSuccess && nb > 0) s->blocksPerCU = nb;
+    if (const char *x = std::getenv("RT_TRAV_EXTRA_LDS")) s->extraLds = (size_t)std::max(0L, std::atol(x));
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_shadow<false>, kBlock, s->extraLds) == hipSuccess && nb > 0) s->blocksPerCU = nb;
+    if (const char *x = std::getenv("RT_TRAV_BLOCKS_PER_CU")) s->blocksPerCU = std::max(1, std::atoi(x));
   }
   if ((e = resolveStaticScratch(device)) != hipSuccess) {
     g_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
@@ -1323,8 +1345,8 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
     uint32_t *qCur = B.qA, *qNext = B.qB;
     for (int bounce = 0; bounce < S.maxBounces; ++bounce) {
       if ((rc = beginEvent(s, CAT_EXTEND, timing))) return rc;
-      if (count) k_extend<true><<<persistentGrid(s, n), kBlock, 0, st>>>(S, B, qCur);
-      else k_extend<false><<<persistentGrid(s, n), kBlock, 0, st>>>(S, B, qCur);
+      if (count) k_extend<true><<<persistentGrid(s, n), kBlock, s->extraLds, st>>>(S, B, qCur);
+      else k_extend<false><<<persistentGrid(s, n), kBlock, s->extraLds, st>>>(S, B, qCur);
       if ((rc = endEvent(s, timing))) return rc;
       ++launchesExtend;
       if ((rc = beginEvent(s, CAT_SHADE, timing))) return rc;
@@ -1333,8 +1355,8 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
       if (S.numLights > 0) {
         if ((rc = beginEvent(s, CAT_SHADOW, timing))) return rc;
         unsigned gridShadow = persistentGrid(s, n * S.numLights);
-        if (count) k_shadow<true><<<gridShadow, kBlock, 0, st>>>(S, B);
-        else k_shadow<false><<<gridShadow, kBlock, 0, st>>>(S, B);
+        if (count) k_shadow<true><<<gridShadow, kBlock, s->extraLds, st>>>(S, B);
+        else k_shadow<false><<<gridShadow, kBlock, s->extraLds, st>>>(S, B);
         if ((rc = endEvent(s, timing))) return rc;
         ++launchesShadow;
       }
@@ -1363,13 +1385,14 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
   if (stats) {
     std::memset(stats, 0, sizeof *stats);
     stats->cameraSamples = hc.samples;
-    stats->raysClosest = hc.raysClosest - hc.skipPoint;
-    stats->raysAny = hc.raysAny - hc.skipAny;
-    stats->raysSkipped = hc.skipPoint + hc.skipAny;
+    stats->raysClosest = hc.raysClosest - hc.skipPoint - hc.planePoint;
+    stats->raysAny = hc.raysAny - hc.skipAny - hc.planeAny;
+    stats->raysSkipped = hc.skipPoint + hc.skipAny + hc.planePoint + hc.planeAny;
+    stats->raysPlaneAnswered = hc.planePoint + hc.planeAny;
     stats->innerExpansions = hc.inner[0] + hc.inner[1];
     stats->primTests = hc.prims[0] + hc.prims[1];
     stats->planeTests = hc.planes[0] + hc.planes[1];
-    stats->raysExtend = hc.raysExtend; stats->raysShadow = hc.raysShadow - hc.skipPoint - hc.skipAny;
+    stats->raysExtend = hc.raysExtend; stats->raysShadow = hc.raysShadow - hc.skipPoint - hc.skipAny - hc.planePoint - hc.planeAny;
     stats->innerExtend = hc.inner[0]; stats->primExtend = hc.prims[0];
     stats->innerShadow = hc.inner[1]; stats->primShadow = hc.prims[1];
     stats->laneUseInnerExtend = hc.innerWaveIters[0] > 0 ? hc.inner[0] / (64.0 * hc.innerWaveIters[0]) : 0.0;
