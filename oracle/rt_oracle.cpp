@@ -114,18 +114,31 @@ struct MtSampler : Sampler {
   std::uniform_real_distribution<float> dist{0, 1.0};
   float next() override { return dist(rng); }
 };
-// Counter-based stream shared with the HIP kernels: state seeded from (seed, pixel, sample), PCG-RXS-M-XS steps.
-inline uint32_t mix32(uint32_t x) {
-  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-  return x;
+// Counter-based stream shared with the HIP kernels: Philox4x32-10 (Salmon et al., SC'11), key (seed, 0), counter
+// (pixel, sample, block, 0); draw number d of a camera sample is word d % 4 of block d / 4.
+inline void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c[4]) {
+  for (int round = 0; round < 10; ++round) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
 }
 struct CounterSampler : Sampler {
-  uint32_t state = 0;
-  void seed(uint32_t seed, uint32_t pixel, uint32_t sample) { state = mix32(mix32(mix32(seed) ^ pixel) ^ sample); }
+  uint32_t seedWord = 0, pixel = 0, sample = 0, draws = 0, block = 0xffffffffu;
+  uint32_t w[4] = {0, 0, 0, 0};
+  void seed(uint32_t seed, uint32_t pixel_, uint32_t sample_) {
+    seedWord = seed; pixel = pixel_; sample = sample_; draws = 0; block = 0xffffffffu;
+  }
   float next() override {
-    state = state * 747796405u + 2891336453u;
-    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
-    word = (word >> 22u) ^ word;
+    const uint32_t b = draws >> 2;
+    if (b != block) {
+      w[0] = pixel; w[1] = sample; w[2] = b; w[3] = 0;
+      philox4x32_10(seedWord, 0u, w);
+      block = b;
+    }
+    const uint32_t word = w[draws & 3u];
+    ++draws;
     return (float)(word >> 8) * (1.0f / 16777216.0f);
   }
 };
@@ -971,6 +984,19 @@ int rto_render(RtoScene *s, const RtRenderParams *params, float *rgbaOut, RtStat
 }
 
 const float *rto_framebuffer_device(RtoScene *s) { return s ? s->framebuffer.data() : nullptr; }
+
+// Test hook: one Philox4x32-10 block, for the known-answer vectors.
+void rto_philox4x32_10(const uint32_t key[2], const uint32_t counter[4], uint32_t out[4]) {
+  uint32_t c[4] = {counter[0], counter[1], counter[2], counter[3]};
+  philox4x32_10(key[0], key[1], c);
+  for (int i = 0; i < 4; ++i) out[i] = c[i];
+}
+// Test hook: the first n draws of camera sample (seed, pixel, sample) as the kernels and rto_render see them.
+void rto_counter_draws(uint32_t seed, uint32_t pixel, uint32_t sample, int32_t n, float *out) {
+  CounterSampler cs;
+  cs.seed(seed, pixel, sample);
+  for (int32_t i = 0; i < n; ++i) out[i] = cs.next();
+}
 
 int rto_device_count(void) { return 0; }  // the CPU restatement uses no GPU
 

@@ -73,17 +73,44 @@ RT_DEV void mulAssign(RGBA &x, RGBA c) { x.r *= c.r; x.g *= c.g; x.b *= c.b; x.a
 RT_DEV void addAssign(RGBA &x, RGBA o) { x.r += o.r; x.g += o.g; x.b += o.b; x.a = rmax(o.a, x.a); }             // :79-85
 RT_DEV bool hasNaN(RGBA c) { return isnan(c.r) || isnan(c.g) || isnan(c.b); }
 
-// Counter-based random stream: one 32-bit state per (seed, pixel, sample), PCG-RXS-M-XS steps, 24-bit floats in
-// [0,1). Keyed on absolute pixel and sample indices, so images do not depend on the tile partition or GPU count.
-RT_DEV uint32_t mix32(uint32_t x) {
-  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-  return x;
+// Counter-based random stream: Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11)
+// with key (seed, 0) and counter (pixel, sample, block, 0). A camera sample's draw number d is word d % 4 of block
+// d / 4, so two draws coincide only if (seed, pixel, sample, d) coincide: the generator is a bijection of the counter
+// for a fixed key. The only state a path carries between kernels is d (how many draws it has consumed); everything
+// else is recomputed from the path's pixel and sample index, so images do not depend on the tile partition, the pass
+// size or the GPU count. 24-bit floats in [0,1).
+struct Rng {
+  uint32_t seed, pixel, sample;
+  uint32_t draws;     // draws consumed so far by this camera sample
+  uint32_t block;     // block held in w, 0xffffffff = none
+  uint32_t w[4];
+};
+RT_DEV void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
+#pragma unroll
+  for (int round = 0; round < 10; ++round) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-RT_DEV uint32_t rngSeed(uint32_t seed, uint32_t pixel, uint32_t sample) { return mix32(mix32(mix32(seed) ^ pixel) ^ sample); }
-RT_DEV float rngNext(uint32_t &state) {
-  state = state * 747796405u + 2891336453u;
-  uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
-  word = (word >> 22u) ^ word;
+RT_DEV Rng rngInit(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t draws) {
+  Rng r;
+  r.seed = seed; r.pixel = pixel; r.sample = sample; r.draws = draws; r.block = 0xffffffffu;
+  r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0u;
+  return r;
+}
+RT_DEV float rngNext(Rng &r) {
+  const uint32_t block = r.draws >> 2;
+  if (block != r.block) {
+    philox4x32_10(r.seed, 0u, r.pixel, r.sample, block, 0u, r.w);
+    r.block = block;
+  }
+  const uint32_t lane = r.draws & 3u;
+  const uint32_t word = lane == 0u ? r.w[0] : lane == 1u ? r.w[1] : lane == 2u ? r.w[2] : r.w[3];
+  ++r.draws;
   return (float)(word >> 8) * (1.0f / 16777216.0f);
 }
 

@@ -22,7 +22,7 @@ RT_DEV V3 transformToWorld(float x, float y, float z, V3 normal) {
 }
 
 // src/bsdf/math_utils.cpp:23-36 (two draws)
-RT_DEV V3 sampleHemisphere(V3 n, uint32_t &rng) {
+RT_DEV V3 sampleHemisphere(V3 n, Rng &rng) {
   float rand = rngNext(rng);
   float r = sqrtf(rand);
   float theta = (float)((double)(rngNext(rng) * 2.0f) * kPi);
@@ -111,7 +111,7 @@ RT_DEV float trLambda(float alpha, V3 w, V3 n) {  // :25-32
   float alpha2Tan2Theta = (alpha * absTanTheta) * (alpha * absTanTheta);
   return (-1 + sqrtf(1 + alpha2Tan2Theta)) / 2;
 }
-RT_DEV V3 trSampleWh(float alpha, V3 wo, V3 n, uint32_t &rng) {  // :34-47 (two draws)
+RT_DEV V3 trSampleWh(float alpha, V3 wo, V3 n, Rng &rng) {  // :34-47 (two draws)
   float rand = rngNext(rng);
   float theta = atanf(alpha * sqrtf(rand / (1.0f - rand)));
   float phi = (float)((double)(rngNext(rng) * 2.0f) * kPi);
@@ -164,7 +164,7 @@ RT_DEV float lobePdf(const DevLobe &l, V3 wo, V3 wi, V3 n) {
   }
   return 0.0f;
 }
-RT_DEV float lobeSample(const DevLobe &l, V3 wo, V3 &wi, V3 n, uint32_t &rng, float &pdf) {
+RT_DEV float lobeSample(const DevLobe &l, V3 wo, V3 &wi, V3 n, Rng &rng, float &pdf) {
   if (l.kind == LOBE_LAMBERT || l.kind == LOBE_OREN_NAYAR) {  // BDF.cpp:13-18
     wi = sampleHemisphere(n, rng);
     pdf = basePdf(wo, wi, n);
@@ -203,7 +203,7 @@ RT_DEV float lobeSample(const DevLobe &l, V3 wo, V3 &wi, V3 n, uint32_t &rng, fl
 
 // BSDF::sampleFunc, src/bsdf/BDF.cpp:133-157 (the branch at :146 is always taken: no lobe's type equals the bare
 // PERFECT_SPECULAR bit)
-RT_DEV float bsdfSample(const DevMaterial &m, V3 wo, V3 &wi, V3 n, uint32_t &rng, float &pdf) {
+RT_DEV float bsdfSample(const DevMaterial &m, V3 wo, V3 &wi, V3 n, Rng &rng, float &pdf) {
   int numBDFs = m.numLobes;
   float rand = floorf(rngNext(rng) * numBDFs);
   int idx = min(numBDFs - 1, (int)rand);

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DevScene S, PathBuf B, const 
     int32_t p = (int32_t)(i % B.npix), s = (int32_t)(i / B.npix);
     int32_t pixel = pixList[p];
     int32_t x = pixel % S.width, y = pixel / S.width;
-    uint32_t rng = rngSeed(seed, (uint32_t)pixel, (uint32_t)(sampleBase + s));
+    Rng rng = rngInit(seed, (uint32_t)pixel, (uint32_t)(sampleBase + s), 0u);
     int allowAA = min(1, S.numRays - 1);
     float Sx = getRayScaleX(x + (rngNext(rng) - 0.5f) * allowAA, S.width, S.height);
     float Sy = getRayScaleY(y + (rngNext(rng) - 0.5f) * allowAA, S.width, S.height);
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DevScene S, PathBuf B, const 
       o = (r * cosf(weight) * S.lens / S.magRight) * right + (r * sinf(weight) * S.lens / S.magUp) * up + eye;
       d = focusPoint - o;
     }
-    B.rng[i] = rng;
+    B.rng[i] = rng.draws;
     B.L[i] = make_float4(0, 0, 0, 0);
     B.beta[i] = make_float4(1, 1, 1, 1);
     if (alive) {
@@ -214,7 +214,7 @@ __global__ RT_TRAV_ATTR void k_extend(DevScene S, PathBuf B, const uint32_t *que
 
 // ---------------------------------------------------------------------------------------------------- k_shade
 __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, PathBuf B, const uint32_t *queue, uint32_t *queueNext,
-                                                  int32_t bounce) {
+                                                  int32_t bounce, const int32_t *pixList, int32_t sampleBase, uint32_t seed) {
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   bool isHit = false, continues = false;
   uint32_t slot = 0;
@@ -225,7 +225,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, PathBuf B, const u
     float4 o4 = B.rayO[slot], d4 = B.rayD[slot];
     int32_t prim = B.hitPrim[slot];
     float t = B.hitT[slot];
-    uint32_t rng = B.rng[slot];
+    // the path's random stream is a function of its pixel and sample index; only the draw count is stored
+    const uint32_t sampleInPass = slot / (uint32_t)B.npix;
+    Rng rng = rngInit(seed, (uint32_t)pixList[slot - sampleInPass * (uint32_t)B.npix], (uint32_t)sampleBase + sampleInPass, B.rng[slot]);
     float4 beta4 = B.beta[slot];
     V3 o = v3(o4.x, o4.y, o4.z), d = v3(d4.x, d4.y, d4.z);
     const bool onObject = prim >= 0 && prim < S.numPrims;
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, PathBuf B, const u
         }
       }
       B.beta[slot] = f4(beta);
-      B.rng[slot] = rng;
+      B.rng[slot] = rng.draws;
     }
   }
   uint32_t qh, qn;
@@ -1350,7 +1352,7 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
       if ((rc = endEvent(s, timing))) return rc;
       ++launchesExtend;
       if ((rc = beginEvent(s, CAT_SHADE, timing))) return rc;
-      k_shade<<<grid, kBlock, 0, st>>>(S, B, qCur, qNext, bounce);
+      k_shade<<<grid, kBlock, 0, st>>>(S, B, qCur, qNext, bounce, s->pixList, sBase, params->seed);
       if ((rc = endEvent(s, timing))) return rc;
       if (S.numLights > 0) {
         if ((rc = beginEvent(s, CAT_SHADOW, timing))) return rc;

@@ -283,3 +283,46 @@ def test_libraries_export_every_declared_symbol():
 def test_device_library_does_not_link_the_oracle():
     out = subprocess.run(["ldd", os.path.join(REPO, "raytracer_amd", "libraytracer_amd.so")], capture_output=True, text=True).stdout
     assert "oracle" not in out and "amdhip64" in out
+
+
+def test_philox_known_answers_and_stream_injectivity():
+    """The counter-mode generator is Philox4x32-10: the three known-answer vectors of the Random123 distribution, and
+    no two camera samples of a 1080 x 1080 x 256 frame share a stream (the counter (pixel, sample, block) is a
+    bijection's input, so equal outputs need equal counters): checked on every sample of 4096 pixels spread over the
+    frame and on 2^20 random (pixel, sample) pairs."""
+    from tests.oracle_binding import load_oracle_library
+    L = load_oracle_library()
+    u32 = C.c_uint32
+
+    def block(key, ctr):
+        out = (u32 * 4)()
+        L.rto_philox4x32_10((u32 * 2)(*key), (u32 * 4)(*ctr), out)
+        return list(out)
+    assert block([0, 0], [0, 0, 0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert block([0xffffffff] * 2, [0xffffffff] * 4) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert block([0xa4093822, 0x299f31d0], [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344]) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    # the first block of a stream, as 4 x 24-bit draws, for many (pixel, sample) pairs: all different
+    L.rto_counter_draws.argtypes = [u32, u32, u32, C.c_int32, C.POINTER(C.c_float)]
+    rng = np.random.default_rng(1)
+    npix = 1080 * 1080
+    pixels = np.concatenate([np.repeat(np.linspace(0, npix - 1, 4096).astype(np.int64), 256), rng.integers(0, npix, 1 << 20)])
+    samples = np.concatenate([np.tile(np.arange(256), 4096), rng.integers(0, 256, 1 << 20)])
+    pairs = np.unique(np.stack([pixels, samples], 1), axis=0)
+    # vectorised restatement of the block function (same constants) so that two million streams take a second
+    def philox(c0, c1, c2, c3, k0, k1):
+        c0, c1, c2, c3 = (np.asarray(x, dtype=np.uint64) for x in (c0, c1, c2, c3))
+        m32 = np.uint64(0xffffffff)
+        for _ in range(10):
+            p0 = np.uint64(0xD2511F53) * c0; p1 = np.uint64(0xCD9E8D57) * c2
+            n0 = (p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0); n2 = (p0 >> np.uint64(32)) ^ c3 ^ np.uint64(k1)
+            c0, c1, c2, c3 = n0, p1 & m32, n2, p0 & m32
+            k0 = (k0 + 0x9E3779B9) & 0xffffffff; k1 = (k1 + 0xBB67AE85) & 0xffffffff
+        return np.stack([c0, c1, c2, c3], 1).astype(np.uint32)
+    words = philox(pairs[:, 0], pairs[:, 1], np.zeros(len(pairs)), np.zeros(len(pairs)), 56, 0)
+    draws = (words >> 8).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    for i in (0, 1, len(pairs) // 2, len(pairs) - 1):  # the vectorised form is the oracle's generator
+        got = (C.c_float * 4)()
+        L.rto_counter_draws(56, int(pairs[i, 0]), int(pairs[i, 1]), 4, got)
+        assert list(got) == list(draws[i])
+    assert len(np.unique(words, axis=0)) == len(pairs), "two camera samples share a random stream"
+    assert len(np.unique(draws, axis=0)) == len(pairs)
