@@ -92,27 +92,77 @@ def test_full_size_benchmark_scene(scenes, golden):
         dev.set_view(options=full); orc.set_view(options=full)
 
 
-def test_config5_shape_4k_multi_million_triangles():
-    """The 10 M-triangle stress configuration in shape (3840x2160, in-memory procedural mesh, GI with point + environment light), at 2 M
-    triangles so that the host build stays short; tools/config5_stress.py runs the 10 M-triangle size."""
-    from tools import config5_stress
-    hs, tris = config5_stress.build_scene(1000, 3840, 2160, 1, 4)
-    hs.build()
-    assert tris > 1_900_000
-    dev, orc = capi.device_scene(hs.desc), oracle_scene(hs.desc)
+def test_config3_full_sample_count_partition_and_pass_sizes(scenes):
+    """The benchmark configuration at its real sample count (1080x1080, 256 samples per pixel): one 64th of the frame's
+    tiles on the GPU and on the oracle at matched streams (PSNR >= 40 dB over the pixels of the partition, alpha exact);
+    the whole frame in one pass (298.6 M paths, what bench.py times) and in 37 passes of 7 samples: the same bits, and
+    the partition's pixels inside it are the partition's render, bit for bit."""
+    hs, dev, orc = scenes("readme")
+    opt = hs.desc.contents.options
+    assert (opt.width, opt.height) == (1080, 1080)
+    full = capi.RtOptions(opt.width, opt.height, opt.bias, opt.exposure, opt.maxBounces, opt.numRays, opt.fisheye, opt.focus, opt.lens)
+    spp256 = capi.RtOptions(opt.width, opt.height, opt.bias, opt.exposure, opt.maxBounces, 256, opt.fisheye, opt.focus, opt.lens)
+    dev.set_view(options=spp256); orc.set_view(options=spp256)
     try:
-        gi, gt = dev.trace_primary(0, 1000, 3840, 96)
-        oi, ot = orc.trace_primary(0, 1000, 3840, 96)
+        from raytracer_amd import multi_gpu
+        own = multi_gpu.tile_owner(opt.width, opt.height, (32, 32), 64) == 5
+        part, st = dev.render(seed=56, part_index=5, part_count=64, tile=(32, 32))
+        ref, ost = orc.render(seed=56, part_index=5, part_count=64, tile=(32, 32))
+        assert st.cameraSamples == ost.cameraSamples == int(own.sum()) * 256
+        assert np.all(part[~own] == 0) and np.all(ref[~own] == 0)
+        assert np.array_equal(part[..., 3], ref[..., 3])
+        p = psnr(part[own][:, :3], ref[own][:, :3])
+        assert p >= PSNR_MIN_DB, f"PSNR {p:.1f} dB over the partition at 256 spp"
+        assert int(st.raysClosest + st.raysAny + st.raysSkipped) == pytest.approx(int(ost.raysClosest + ost.raysAny), rel=2e-3)
+        part7, st7 = dev.render(seed=56, part_index=5, part_count=64, tile=(32, 32), samples_per_pass=7)
+        assert st7.passes == 37 and st.passes == 1
+        assert np.array_equal(part7.view(np.uint32), part.view(np.uint32))
+        whole, stw = dev.render(seed=56)
+        assert stw.passes == 1 and stw.cameraSamples == 1080 * 1080 * 256
+        assert np.array_equal(whole[own].view(np.uint32), part[own].view(np.uint32))
+        whole7, stw7 = dev.render(seed=56, samples_per_pass=7)
+        assert stw7.passes == 37
+        assert np.array_equal(whole7.view(np.uint32), whole.view(np.uint32)), "pass size changes the 256-spp frame"
+        assert np.isfinite(whole).all() and whole.min() >= 0.0 and whole.max() <= 1.0
+    finally:
+        dev.set_view(options=full); orc.set_view(options=full)
+
+
+def test_config5_full_size_10M_triangles_4k_64spp():
+    """The stress configuration at its real size: ~10 M triangles built in memory, 3840x2160, 64 samples per pixel,
+    multi-bounce GI with a point and an environment light. Primary hits of a 64-row band and incoherent closest / any
+    queries bit-exact against the oracle on the same scene description; the 64-spp frame recombines bit for bit from
+    an 8-way tile partition; one partition at 64 spp within the PSNR bar of the oracle."""
+    from raytracer_amd import multi_gpu
+    from tools import config5_stress
+    W, H, SPP = 3840, 2160, 64
+    hs, tris = config5_stress.build_scene(2237, W, H, SPP, 4)
+    hs.build()
+    assert tris > 9_900_000 and hs.desc.contents.numNodes > 6_000_000
+    dev, orc = capi.device_scene(hs.desc), oracle_scene(hs.desc, threads=16)
+    try:
+        gi, gt = dev.trace_primary(0, 1048, W, 64)
+        oi, ot = orc.trace_primary(0, 1048, W, 64)
         assert (gi >= 0).sum() > 100_000
         assert np.array_equal(gi, oi) and np.array_equal(gt.view(np.uint32), ot.view(np.uint32))
         o, d = _random_rays(100_000, 23)
         for a, b in zip(dev.trace_closest(o, d), orc.trace_closest(o, d)):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
-        img, st = dev.render(seed=9)
-        whole = img.copy()
-        parts = sum(dev.render(seed=9, part_index=r, part_count=8, tile=(32, 32))[0] for r in range(8))
-        assert np.array_equal(parts.view(np.uint32), whole.view(np.uint32)), "8-way tile partition must recombine exactly"
-        assert st.cameraSamples == 3840 * 2160
+        assert np.array_equal(dev.trace_any(o, d), orc.trace_any(o, d))
+        whole, st = dev.render(seed=9)
+        assert st.cameraSamples == W * H * SPP
+        assert np.isfinite(whole).all() and whole.min() >= 0.0 and whole.max() <= 1.0
+        acc = np.zeros_like(whole)
+        for r in range(8):
+            acc += dev.render(seed=9, part_index=r, part_count=8, tile=(32, 32))[0]
+        assert np.array_equal(acc.view(np.uint32), whole.view(np.uint32)), "8-way tile partition must recombine exactly at 64 spp"
+        # one 512th of the tiles (~16 k pixels) at the full 64 spp against the oracle
+        own = multi_gpu.tile_owner(W, H, (32, 32), 512) == 131
+        part, _ = dev.render(seed=9, part_index=131, part_count=512, tile=(32, 32))
+        ref, _ = orc.render(seed=9, part_index=131, part_count=512, tile=(32, 32))
+        assert np.array_equal(part[own].view(np.uint32), whole[own].view(np.uint32))
+        assert np.array_equal(part[..., 3], ref[..., 3])
+        assert psnr(part[own][:, :3], ref[own][:, :3]) >= PSNR_MIN_DB
     finally:
         dev.close(); orc.close()
 
