@@ -174,17 +174,21 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    rays_local = sum(s.raysClosest + s.raysAny for s in stats)
+    # A ray = one visibility / closest-hit query answered by intersecting scene geometry (the reference's
+    # Scene::findClosestObject / findAnyObject call): queries that traversed the BVH plus queries a plane of the scene
+    # settled before the BVH was needed. Queries skipped because their light contributes exactly nothing are NOT counted.
+    rays_local = sum(s.raysClosest + s.raysAny + s.raysPlaneAnswered for s in stats)
+    traversed_local = sum(s.raysClosest + s.raysAny for s in stats)
     samples_local = sum(s.cameraSamples for s in stats)
-    agg = torch.tensor([float(elapsed), float(rays_local), float(samples_local)], dtype=torch.float64, device=tdev)
+    agg = torch.tensor([float(elapsed), float(rays_local), float(samples_local), float(traversed_local)], dtype=torch.float64, device=tdev)
     if world > 1:
         tmax = agg[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         sums = agg[1:].clone()
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        elapsed, rays_total, samples_total = float(tmax[0]), float(sums[0]), float(sums[1])
+        elapsed, rays_total, samples_total, traversed_total = float(tmax[0]), float(sums[0]), float(sums[1]), float(sums[2])
     else:
-        rays_total, samples_total = float(rays_local), float(samples_local)
+        rays_total, samples_total, traversed_total = float(rays_local), float(samples_local), float(traversed_local)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -211,25 +215,51 @@ def main():
         kname, kb, kms, krays, klaunch = "k_extend", b_ext, ms_ext, rays_ext, launches_ext
     else:
         kname, kb, kms, krays, klaunch = "k_shadow", b_sh, ms_sh, rays_sh, launches_sh
-    achieved = (krays * kb) / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-    # HBM bytes per launch from the PMC passes of this same workload (tools/profile_on_box.sh -> tools/pmc_traffic.py);
-    # counters cannot be read from inside this process, so the figure is the committed one, and only for the default run.
-    traffic = None
+    # What binds the traversal kernels is measured, not assumed: the hardware counters of this same command
+    # (tools/profile_on_box.sh -> tools/pmc_traffic.py -> profiles/pmc_traffic.json; counters cannot be read from inside
+    # this process) say how busy the vector ALUs, the L1 caches and the memory side are. They are reported only for the
+    # profiled workload and only while the kernel sources still hash to what was profiled; kernel time and the
+    # per-ray work are measured live, here.
+    from tools import pmc_traffic
+    prof = None
     tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
     default_workload = (args.spp, args.size, args.grid, args.spp_pass, args.tile, world) == (256, 1080, 512, 0, 32, 1)
     if default_workload and os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath))["kernels"][kname]["hbm_bytes_per_launch"]
+            pj = json.load(open(tpath))
+            if pj.get("source_sha1") == pmc_traffic.source_sha1():
+                prof = pj["kernels"][kname]
         except (KeyError, ValueError):
-            traffic = None
+            prof = None
+    inner, prims = (cst.innerExtend, cst.primExtend) if kname == "k_extend" else (cst.innerShadow, cst.primShadow)
+    lu_i, lu_p = ((cst.laneUseInnerExtend, cst.laneUsePrimExtend) if kname == "k_extend" else (cst.laneUseInnerShadow, cst.laneUsePrimShadow))
+    lane_use = (inner + prims) / (inner / lu_i + prims / lu_p) if lu_i > 0 and lu_p > 0 else None
+    avg_ms = kms / max(1, klaunch)
+    L1_PEAK = 1.45  # L1 accesses per clock per CU, every access a hit on a different line (tools/micro/l1_access_probe.hip)
     roofline = {
-        "bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/pmc_traffic.json)",
-        "algorithmic_bytes_per_launch": int(krays * kb / max(1, klaunch)),
+        "bound": "valu_issue", "kernel": kname, "unit": "fraction of vector-ALU issue cycles in use (SQ_ACTIVE_INST_VALU)", "peak": 1.0,
+        "achieved": prof.get("valu_busy") if prof else None,
+        "frac": prof.get("valu_busy") if prof else None,
+        "useful_frac": round(prof["valu_busy"] * lane_use, 4) if prof and prof.get("valu_busy") and lane_use else None,
+        "lane_use": round(lane_use, 4) if lane_use else None,
+        "lane_use_by_loop": {"extend_inner": round(cst.laneUseInnerExtend, 3), "extend_prim": round(cst.laneUsePrimExtend, 3),
+                             "shadow_inner": round(cst.laneUseInnerShadow, 3), "shadow_prim": round(cst.laneUsePrimShadow, 3)},
+        "l1": ({"accesses_per_clk_per_cu": round(prof["l1_access_busy"], 4), "peak": L1_PEAK,
+                "frac": round(prof["l1_access_busy"] / L1_PEAK, 4)} if prof and "l1_access_busy" in prof else None),
+        "hbm": ({"bound": "hbm", "achieved": round(prof["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(prof["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "traffic": prof["hbm_bytes_per_launch"], "traffic_unit": "bytes per launch (FETCH_SIZE as counted for scattered 64-byte "
+                 "records, see tools/pmc_traffic.py, + WRITE_SIZE)"} if prof else None),
+        "traffic": prof["hbm_bytes_per_launch"] if prof else None,
+        "profile": ({"file": "profiles/pmc_traffic.json", "avg_launch_ms": round(prof.get("trace_avg_us", 0) / 1e3, 4),
+                     "valu_instr_per_ray": round(prof["valu_instr_per_launch"] / (krays / max(1, klaunch)), 1) if "valu_instr_per_launch" in prof else None}
+                    if prof else "no counters for this workload / these kernel sources: rerun tools/profile_on_box.sh"),
+        # what a cache-less machine would have to fetch: every node visit 64 B, every object test 48 B (served by L1/L2 here)
+        "algorithmic_cache_bytes_per_launch": int(krays * kb / max(1, klaunch)),
+        "algorithmic_cache_GBps": round((krays * kb) / (kms * 1e-3) / 1e9, 1) if kms > 0 else None,
         "bytes_per_ray": round(kb, 1), "rays_per_launch": round(krays / max(1, klaunch), 1),
-        "avg_launch_ms": round(kms / max(1, klaunch), 4),
-        "lane_use": {"extend_inner": round(cst.laneUseInnerExtend, 3), "extend_prim": round(cst.laneUsePrimExtend, 3),
-                     "shadow_inner": round(cst.laneUseInnerShadow, 3), "shadow_prim": round(cst.laneUsePrimShadow, 3)}, "mrays_per_s_in_kernel": round(krays / (kms * 1e-3) / 1e6, 1) if kms > 0 else 0.0,
+        "avg_launch_ms": round(avg_ms, 4),
+        "mrays_per_s_in_kernel": round(krays / (kms * 1e-3) / 1e6, 1) if kms > 0 else 0.0,
         "other_kernel": {"kernel": "k_shadow" if kname == "k_extend" else "k_extend",
                          "bytes_per_ray": round(b_sh if kname == "k_extend" else b_ext, 1),
                          "ms_total": round(ms_sh if kname == "k_extend" else ms_ext, 2),
@@ -279,12 +309,16 @@ def main():
                                   + ("RCCL gather to rank 0" if backend == "nccl" else f"REHEARSAL: {backend} gather, ranks share GPUs")},
         "wall_time_s": round(ms_per_step / 1e3, 3),
         "camera_msamples_per_s": round(samples_total / elapsed / 1e6, 2),
+        "value_definition": "queries answered by intersecting scene geometry per second: BVH-traversed + settled by a plane before "
+                            "the BVH; zero-contribution queries the reference also traces are excluded",
+        "mrays_bvh_traversed_per_s": round(traversed_total / elapsed / 1e6, 2),
         "rays_per_frame": int(rays_total / args.steps),
+        "rays_bvh_traversed_per_frame": int(traversed_total / args.steps),
         # visibility queries the reference traces and this library answers without a traversal (zero contribution, or a
         # plane alone decides); `value` counts traversed queries only
         "rays_skipped_per_frame": int(sum(s.raysSkipped for s in stats) / args.steps),
         "rays_plane_answered_per_frame": int(sum(s.raysPlaneAnswered for s in stats) / args.steps),
-        "reference_queries_per_frame": int((rays_total + sum(s.raysSkipped for s in stats)) / args.steps) if world == 1 else None,
+        "reference_queries_per_frame": int((traversed_total + sum(s.raysSkipped for s in stats)) / args.steps) if world == 1 else None,
         "rays_per_camera_sample": round(rays_total / max(1.0, samples_total), 3),
         "kernel_ms_per_frame": {k: round(sum(getattr(s, k) for s in stats) / args.steps, 2)
                                 for k in ("msTotal", "msRaygen", "msExtend", "msShade", "msShadow", "msDirect", "msAccumulate", "msResolve")},
