@@ -2,14 +2,18 @@
 //
 //   nodes      one 64-byte record per INNER node of the reference's BVH (src/acceleration/BVH.h:49-61): the boxes of
 //              both children plus a packed reference to each, so that one inner step is one 64-byte fetch instead of
-//              the two 32-byte fetches (left at idx+1, right far away) the pre-order array needs. Inner records are
-//              numbered in pre-order, which keeps a subtree contiguous. Four float4 per record:
+//              the two 32-byte fetches (left at idx+1, right far away) the pre-order array needs. The first
+//              numTopNodes records are the top of the tree in breadth-first order (every workgroup copies them into
+//              LDS); the others follow in pre-order, which keeps a subtree contiguous. Four float4 per record:
 //                [0] lmin.xyz lmax.x   [1] lmax.yz rmin.xy   [2] rmin.z rmax.xyz   [3] leftRef rightRef 0 0 (as ints)
 //   primHit    48 bytes per BVH object, in BVH order, three float4:
 //                triangle: p1.xyz n.x | n.yz e1.xy | e1.z e2.xyz        (src/scene/Object.h:162-165)
 //                sphere:   c.xyz 0    | 0 0 r 0    | 0 0 0 0            (src/scene/Object.h:119-120)
 //              A triangle's unit normal is never the all-zero vector (a degenerate one is NaN), so three zero words in
 //              the normal slot identify a sphere without a separate kind array in the hot loop.
+//   primShade  64 bytes per BVH object, 64-byte aligned, four float4 — everything shading reads of an object besides
+//              its hit record, in one memory sector:
+//                n1.xyz n2.x | n2.yz n3.xy | n3.z color.rgb | color.a material texture originalIndex (last three as ints)
 //   child reference (int32):
 //                >= 0                              index of an inner record
 //                bit31 | count<<24 | start         leaf with 1..127 objects starting below 2^24
@@ -68,6 +72,7 @@ struct DevScene {
   const float4 *nodes;
   const float4 *primHit;
   const BigLeaf *bigLeaves;
+  int32_t numTopNodes;  // inner records 0 .. numTopNodes-1 are the top of the tree in breadth-first order (kept in LDS by the kernels)
   int32_t rootRef;  // packed reference of the root; 0x7fffffff = no BVH (no objects)
   float rootMin[3], rootMax[3];
   int32_t numPrims;
@@ -76,12 +81,8 @@ struct DevScene {
   int32_t numPlanes;
   const DevPlane *planes;
   // shading
-  const float *primNormals;    // 9 per object
+  const float4 *primShade;     // 64-byte shading record per object (see above), read once per hit
   const float *primTexCoords;  // 9 per object or nullptr
-  const float4 *primColor;
-  const int32_t *primMaterial;
-  const int32_t *primTexture;
-  const int32_t *primOrigIndex;
   const DevMaterial *materials;
   int32_t numLights, numEnvLights, numPointLights, numAnyLights;
   const DevLight *lights;

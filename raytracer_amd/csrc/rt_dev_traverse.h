@@ -11,6 +11,8 @@
 // The per-lane stack keeps its top K entries in LDS (8 bytes each: entry distance + node reference, one column per
 // lane, so no bank conflicts between lanes) and spills older entries to per-lane scratch memory.
 #pragma once
+#include <type_traits>
+
 #include "rt_dev_scene.h"
 
 namespace rtd {
@@ -40,6 +42,7 @@ RT_DEV float intersectAABB(V3 o, V3 inv, float mnx, float mny, float mnz, float 
 struct TravCounters {
   uint32_t planeAnsweredPoint, planeAnsweredAny;  // always counted: visibility queries the planes answered (no BVH traversal)
   uint32_t inner, prims, planes;
+  uint32_t innerTop;  // inner-node expansions served from the LDS copy of the tree top
   // wave-level iteration counts (each active lane adds 1/active, so the wave sums to 1 per iteration): with `inner`
   // and `prims` they give the fraction of the 64 lanes doing useful work in the two hot loops
   float innerWaveIters, primWaveIters;
@@ -92,12 +95,40 @@ RT_DEV float intersectAABBFinite(V3 o, V3 inv, float mnx, float mny, float mnz, 
   return (tmax >= tmin && tmax > 0) ? tmin : kInf;
 }
 
+// The two slab tests above without their final select: entry and exit parameter of the box, for callers that fold
+// "the box is hit" into their own comparison chain (hit <=> tmax >= tmin && tmax > 0).
+RT_DEV void slabExact(V3 o, V3 inv, float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float &tmin, float &tmax) {
+  float tx_near = (mnx - o.x) * inv.x, tx_far = (mxx - o.x) * inv.x;
+  tmin = rmin(tx_near, tx_far); tmax = rmax(tx_near, tx_far);
+  float ty_near = (mny - o.y) * inv.y, ty_far = (mxy - o.y) * inv.y;
+  tmin = rmax(tmin, rmin(ty_near, ty_far)); tmax = rmin(tmax, rmax(ty_near, ty_far));
+  float tz_near = (mnz - o.z) * inv.z, tz_far = (mxz - o.z) * inv.z;
+  tmin = rmax(tmin, rmin(tz_near, tz_far)); tmax = rmin(tmax, rmax(tz_near, tz_far));
+}
+RT_DEV void slabFinite(V3 o, V3 inv, float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float &tmin, float &tmax) {
+  float tx_near = (mnx - o.x) * inv.x, tx_far = (mxx - o.x) * inv.x;
+  float ty_near = (mny - o.y) * inv.y, ty_far = (mxy - o.y) * inv.y;
+  float tz_near = (mnz - o.z) * inv.z, tz_far = (mxz - o.z) * inv.z;
+  tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx_near, tx_far), __builtin_fminf(ty_near, ty_far)), __builtin_fminf(tz_near, tz_far));
+  tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx_near, tx_far), __builtin_fmaxf(ty_near, ty_far)), __builtin_fmaxf(tz_near, tz_far));
+}
+
 #ifndef RT_CHUNK_MAX
 #define RT_CHUNK_MAX 256
 #endif
 #ifndef RT_CHUNK_DIV
 #define RT_CHUNK_DIV 16
 #endif
+// A queue is handed out in kQueueSegments equal, contiguous segments with a ticket counter each (128 bytes apart). A
+// workgroup starts in segment blockIdx.x % kQueueSegments — workgroups are dealt round-robin to the eight accelerator
+// dies (XCDs), each with an L2 of its own — and moves on to the next segment when its own is used up. Queues are in
+// image order, so a die's wavefronts trace rays that start in one band of the image and its L2 holds that band's
+// part of the tree instead of a copy of what the other seven hold.
+#ifndef RT_QUEUE_SEGMENTS
+#define RT_QUEUE_SEGMENTS 8
+#endif
+constexpr int kQueueSegments = RT_QUEUE_SEGMENTS;
+constexpr int kTicketStride = 32;  // dwords between the ticket counters of neighbouring segments
 constexpr uint32_t kTicketChunkMax = RT_CHUNK_MAX, kTicketChunkMin = 64, kChunksPerWave = RT_CHUNK_DIV;  // a prepare step takes up to 64 indices: a chunk must cover one
 
 enum { TRAV_CLOSEST = 0, TRAV_ANY = 1, TRAV_POINT_LIGHT = 2, TRAV_SKIP = 3 };
@@ -118,13 +149,24 @@ enum { TRAV_CLOSEST = 0, TRAV_ANY = 1, TRAV_POINT_LIGHT = 2, TRAV_SKIP = 3 };
 #ifndef RT_DONE_BREAK
 #define RT_DONE_BREAK 12
 #endif
+#ifndef RT_MERGED
+#define RT_MERGED 1
+#endif
+#ifndef RT_MERGED_BREAK
+#define RT_MERGED_BREAK 8
+#endif
 #ifndef RT_TAKE_MIN
 #define RT_TAKE_MIN 8
 #endif
+#ifndef RT_TOP_NODES
+#define RT_TOP_NODES 0
+#endif
+constexpr int kTopNodes = RT_TOP_NODES;      // inner records of the tree top every workgroup keeps in LDS (0 = none)
 constexpr int kPoolSlots = RT_POOL_SLOTS;    // prepared queries a wavefront keeps in LDS (power of two)
 constexpr int kPoolFields = 13;   // dwords per prepared query
 constexpr int kPoolLow = RT_POOL_LOW;      // prepare more queries once at most this many are left
 constexpr int kDoneBreak = RT_DONE_BREAK;  // a phase loop ends early once this many lanes have finished their query
+constexpr int kMergedBreak = RT_MERGED_BREAK;  // merged stepping stops for a service step once this many lanes have no work
 constexpr int kTakeMin = RT_TAKE_MIN;      // lanes without work (done or idle) before results are written and new queries taken
 
 // Limits the host checks before a scene reaches the GPU (rt_scene_create): node and object records are addressed
@@ -169,9 +211,82 @@ constexpr int kMaxTreeDepth = kMaxStack;
 //   uint32_t fetch(uint32_t idx, V3 &o, V3 &d, int &mode, float &bulbDist) load query idx, return a tag for store()
 //   void store(uint32_t tag, HitRec hit, bool occluded, V3 o, V3 nd)       deliver its result
 //
-// LDS the caller provides: ldsStack = K * BLOCK uint2 (stack columns), ldsPool = (BLOCK / 64) * kPoolFields * kPoolSlots dwords.
+// LDS the caller provides: ldsStack = K * BLOCK uint2 (stack columns), ldsPool = (BLOCK / 64) * kPoolFields * kPoolSlots dwords,
+// ldsTop = 4 * max(kTopNodes, 1) float4. The inner records 0 .. S.numTopNodes-1 (the top of the tree in breadth-first order,
+// which every query walks through) are copied into ldsTop once per workgroup: the vector cache serves a scattered
+// 16-byte access per lane at ~1.2-1.5 per clock and CU and is the unit these kernels saturate, LDS serves about twice as
+// many and runs beside it. Must be called by every thread of the workgroup (it synchronises once, before the first query).
+// Lane states of the traversal engine (see traverseQueue).
+enum { OP_IDLE = 0, OP_INNER = 1, OP_PRIM = 2, OP_DONE = 3, OP_DONE_EARLY = 4 };
+
+// One INNER operation on the record (a, b, c, r) of the lane's current node: both child boxes, then descend, push or
+// pop. A leaf reached here is only noted (pi = its reference, pe = 0); its object range is decoded when the lane's
+// first PRIM operation runs. A free function with the lane state passed by reference (not a lambda of traverseQueue):
+// the compiler keeps every one of these in registers this way.
+template <bool EXACT, int K, int BLOCK>
+RT_DEV void innerStep(float4 a, float4 b, float4 c, int4 r, V3 o, V3 inv, float lim, uint2 *stackCol, uint2 *spill, int &sp, int &lo,
+                      int32_t &cur, int32_t &pi, int32_t &pe, int &op) {
+  float tminL, tmaxL, tminR, tmaxR;
+  if (EXACT) {
+    slabExact(o, inv, a.x, a.y, a.z, a.w, b.x, b.y, tminL, tmaxL);
+    slabExact(o, inv, b.z, b.w, c.x, c.y, c.z, c.w, tminR, tmaxR);
+  } else {
+    slabFinite(o, inv, a.x, a.y, a.z, a.w, b.x, b.y, tminL, tmaxL);
+    slabFinite(o, inv, b.z, b.w, c.x, c.y, c.z, c.w, tminR, tmaxR);
+  }
+  // A child is visited if its box is hit (src/acceleration/BVH.cpp:390-409: tmax >= tmin && tmax > 0) at an entry
+  // distance below the closest hit (`lim`); near child first, right only if strictly nearer (:322-333). A child that
+  // cannot beat the closest hit any more is dropped here instead of at pop time.
+  const bool hl = tmaxL >= tminL && tmaxL > 0 && tminL < lim;
+  const bool hr = tmaxR >= tminR && tmaxR > 0 && tminR < lim;
+  const bool both = hl && hr;
+  const bool swap = both && tminR < tminL;
+  if (both) {
+    if (sp - lo == K) { spill[lo] = stackCol[(lo & (K - 1)) * BLOCK]; ++lo; }
+    stackCol[(sp & (K - 1)) * BLOCK] = make_uint2(__float_as_uint(swap ? tminL : tminR), (uint32_t)(swap ? r.x : r.y));
+    ++sp;
+  }
+  int32_t next = (hl && !swap) ? r.x : r.y;
+  if (!(hl || hr)) {
+    next = kNoBvh;
+    while (sp > 0) {
+      --sp;
+      // A spilled entry is first copied back into its LDS slot (rare), so that the read below is always a plain LDS read
+      uint2 *slot = stackCol + (sp & (K - 1)) * BLOCK;
+      if (sp < lo) { lo = sp; *slot = spill[sp]; }
+      uint2 e = *slot;
+      if (__uint_as_float(e.x) < lim) { next = (int32_t)e.y; break; }
+    }
+  }
+  if (next < 0) { pi = next; pe = 0; op = OP_PRIM; }
+  else if (next == kNoBvh) op = OP_DONE;
+  else cur = next;
+}
+
+// One PRIM operation on the record (a, b, c) of object pi (expanded inside traverseQueue, where the lane state lives).
+#define RT_PRIM_STEP()                                                                                              \
+  do {                                                                                                              \
+    bool accepted = intersectPrim(S, a, b, c, pi, o, nd, tBest, primBest);                                          \
+    ++pi;                                                                                                           \
+    if (RUNTIME_MODE && accepted && mode != TRAV_CLOSEST) {                                                         \
+      if (mode == TRAV_ANY) {                                                                                       \
+        op = OP_DONE_EARLY;                                                                                         \
+      } else {                                                                                                      \
+        /* |point - info.point| < |center - point| with info.point = t * nd + origin (src/scene/Object.cpp:22-24) */ \
+        V3 hp = tBest * nd + o;                                                                                     \
+        if (magnitude(o - hp) < bulbDist) op = OP_DONE_EARLY;                                                       \
+      }                                                                                                             \
+    }                                                                                                               \
+    if (op == OP_PRIM && pi == pe) popNext();                                                                       \
+  } while (0)
+
 template <class Source, bool RUNTIME_MODE, bool COUNT, int K, int BLOCK>
-RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint2 *ldsStack, uint32_t *ldsPool, TravCounters &tc) {
+RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint2 *ldsStack, uint32_t *ldsPool, float4 *ldsTop, TravCounters &tc) {
+  const int32_t topCount = kTopNodes > 0 ? S.numTopNodes : 0;
+  if (kTopNodes > 0) {
+    for (int i = threadIdx.x; i < topCount * 4; i += BLOCK) ldsTop[i] = S.nodes[i];
+    __syncthreads();
+  }
   static_assert((K & (K - 1)) == 0, "K must be a power of two");
   static_assert((kPoolSlots & (kPoolSlots - 1)) == 0 && kPoolSlots <= 64, "pool size");
   const uint32_t total = src.total();
@@ -181,7 +296,6 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
   uint2 *stackCol = ldsStack + threadIdx.x;
   uint32_t *pool = ldsPool + (threadIdx.x >> 6) * (kPoolFields * kPoolSlots);  // [field][slot]
   uint2 spill[kMaxStack - K];
-  enum { OP_IDLE = 0, OP_INNER = 1, OP_PRIM = 2, OP_DONE = 3, OP_DONE_EARLY = 4 };
   int op = OP_IDLE;
   uint32_t item = 0;
   V3 o = v3(0, 0, 0), nd = o, inv = o;
@@ -195,21 +309,26 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
   bool exhausted = false;  // wave-uniform: the queue has no more queries
   bool waveExact = false;  // wave-uniform: some lane holds a ray the min/max slab test is not valid for
   uint32_t chunkPos = 0, chunkEnd = 0;
+  uint32_t seg = blockIdx.x % (uint32_t)kQueueSegments, segsLeft = (uint32_t)kQueueSegments;  // wave-uniform
   uint32_t poolHead = 0, poolCount = 0;  // wave-uniform ring of prepared queries
   const uint32_t kTicketChunk = min(kTicketChunkMax, max(kTicketChunkMin, total / (gridDim.x * (BLOCK / 64) * kChunksPerWave)));
 
+  // object range [pi, pe) of a leaf reference (pe > 0 always: a leaf holds at least one object)
+  auto setLeaf = [&](int32_t leaf) {
+    int32_t count = (leaf >> 24) & 0x7f;
+    pi = leaf & 0xffffff;
+    if (count == 0) {
+      BigLeaf bl = S.bigLeaves[leaf & 0x7fffffff];
+      pi = bl.start; count = bl.count;
+    }
+    pe = pi + count;
+  };
   // an inner node becomes an INNER operation, a leaf a run of PRIM operations
   auto enter = [&](int32_t next) {
     if (next >= 0) {
       cur = next; op = OP_INNER;
     } else {
-      int32_t count = (next >> 24) & 0x7f;
-      pi = next & 0xffffff;
-      if (count == 0) {
-        BigLeaf bl = S.bigLeaves[next & 0x7fffffff];
-        pi = bl.start; count = bl.count;
-      }
-      pe = pi + count;
+      setLeaf(next);
       op = OP_PRIM;
     }
   };
@@ -244,6 +363,12 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
     src.store(tag, h, occluded, qo, qnd);
   };
 
+  // INNER phase: every lane with op == OP_INNER expands its node once per iteration, until too few such lanes are left.
+  // A leaf reached here is only noted (pi = its reference, pe = 0); its object range is decoded when the lane's first
+  // PRIM operation runs, outside this loop.
+  // One INNER operation on the record (a, b, c, r) of node `cur`.
+  float4 a = make_float4(0, 0, 0, 0), b = a, c = a;  // the record the current step works on
+  int4 r = make_int4(0, 0, 0, 0);
   while (true) {
     const int nWorking = __popcll(__ballot(op == OP_INNER || op == OP_PRIM));
     const bool service = 64 - nWorking >= kTakeMin || nWorking == 0;
@@ -261,16 +386,33 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
       const uint32_t want = (uint32_t)kPoolSlots - poolCount;  // <= 64
       const uint32_t avail = chunkEnd - chunkPos;
       uint32_t idx = chunkPos + laneId;
+      bool fresh = false;  // lanes >= avail got an index from a new chunk
       if (avail < want) {
-        // Queue indices come from a wave-local chunk [chunkPos, chunkEnd); one atomic on the shared counter buys
-        // kTicketChunk of them, so the counter (a single address all wavefronts hit) sees few operations.
-        uint32_t base = 0;
-        if (laneId == 0) base = atomicAdd(ticket, kTicketChunk);
-        base = __shfl(base, 0);
-        if (laneId >= avail) idx = base + (laneId - avail);
-        chunkPos = base + (want - avail);
-        chunkEnd = base + kTicketChunk;
-        if (base >= total) { exhausted = true; chunkPos = chunkEnd = 0; }
+        // Queue indices come from a wave-local chunk [chunkPos, chunkEnd); one atomic on a shared counter buys
+        // kTicketChunk of them, so the counters (single addresses many wavefronts hit) see few operations.
+        uint32_t base = 0, end = 0;
+        while (segsLeft > 0) {
+          const uint32_t segStart = (uint32_t)(((uint64_t)total * seg) / (uint32_t)kQueueSegments);
+          const uint32_t segEnd = (uint32_t)(((uint64_t)total * (seg + 1)) / (uint32_t)kQueueSegments);
+          uint32_t got = 0;
+          if (laneId == 0) got = atomicAdd(ticket + seg * kTicketStride, kTicketChunk);
+          got = __shfl(got, 0);
+          if (got < segEnd - segStart) {
+            base = segStart + got;
+            end = min(base + kTicketChunk, segEnd);
+            break;
+          }
+          seg = (seg + 1) % (uint32_t)kQueueSegments;
+          --segsLeft;
+        }
+        if (segsLeft == 0) {
+          exhausted = true; chunkPos = chunkEnd = 0;
+        } else {
+          fresh = true;
+          if (laneId >= avail) idx = base + (laneId - avail);
+          chunkPos = min(base + (want - avail), end);
+          chunkEnd = end;
+        }
       } else {
         chunkPos += want;
       }
@@ -281,7 +423,7 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
       int qmode = TRAV_CLOSEST;
       bool qfinite = true;
       uint32_t qitem = 0;
-      if (laneId < want && idx < total) {
+      if (laneId < want && (laneId < avail || (fresh && idx < chunkEnd))) {
         V3 d;
         qitem = src.fetch(idx, qo, d, qmode, qbulb);
         if (!(RUNTIME_MODE && qmode == TRAV_SKIP)) {
@@ -387,64 +529,77 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
     // measured best on MI355X (a PRIM phase is short, so running it almost dry costs little and saves votes)
     const int stayInner = ((nInner + nPrim) * RT_STAY_INNER) >> 3, stayPrim = ((nInner + nPrim) * RT_STAY_PRIM) >> 3;
     const bool canRefill = poolCount > 0 || !exhausted;  // a finished lane can be given a new query at the next vote
+#if RT_MERGED
+    // ------------------------------------------------------------------ one step for every lane that has work
+    // The kernels are bound by the latency of the scattered record fetches (throughput follows the number of wavefronts
+    // in flight, the vector ALU is busy about half of the time), so what counts is the number of fetch round trips per
+    // query: every lane with work fetches its record — a node or an object, same registers — in the same round trip,
+    // and then each kind runs its own code.
+    {
+      int nWork = nInner + nPrim;
+      do {
+        const bool isInner = op == OP_INNER, isPrim = op == OP_PRIM;
+        if (isPrim && pe == 0) setLeaf(pi);  // a leaf an INNER step only noted
+        if (isInner || isPrim) {
+          const float4 *R = reinterpret_cast<const float4 *>(isInner ? nodeBase + ((uint32_t)cur << 6) : primBase + (uint32_t)pi * 48u);
+          a = R[0]; b = R[1]; c = R[2];
+          if (isInner) r = reinterpret_cast<const int4 *>(R)[3];
+        }
+        if (isInner) {
+          if (COUNT) { ++tc.inner; tc.innerWaveIters += 1.0f / (float)nWork; }
+          const float lim = RUNTIME_MODE ? __builtin_fminf(tBest, cullD) : tBest;
+          if (waveExact) innerStep<true, K, BLOCK>(a, b, c, r, o, inv, lim, stackCol, spill, sp, lo, cur, pi, pe, op);
+          else innerStep<false, K, BLOCK>(a, b, c, r, o, inv, lim, stackCol, spill, sp, lo, cur, pi, pe, op);
+        }
+        if (isPrim) {
+          if (COUNT) { ++tc.prims; tc.primWaveIters += 1.0f / (float)nWork; }
+          RT_PRIM_STEP();
+        }
+        nWork = __popcll(__ballot(op == OP_INNER || op == OP_PRIM));
+      } while (nWork > 0 && !(canRefill && 64 - nWork >= kMergedBreak));
+    }
+    continue;
+#endif
     if (nInner >= nPrim) {
       // ---------------------------------------------------------------- INNER: both child boxes of the current node
       int n = nInner;
       do {
         if (op == OP_INNER) {
           if (COUNT) { ++tc.inner; tc.innerWaveIters += 1.0f / (float)n; }
-          const float4 *N = reinterpret_cast<const float4 *>(nodeBase + ((uint32_t)cur << 6));
-          float4 a = N[0], b = N[1], c = N[2];
-          int4 r = reinterpret_cast<const int4 *>(N)[3];
-          float dl, dr;
-          if (waveExact) {  // wave-uniform: the compare-and-select form is valid for every ray, just slower
-            dl = intersectAABB(o, inv, a.x, a.y, a.z, a.w, b.x, b.y);
-            dr = intersectAABB(o, inv, b.z, b.w, c.x, c.y, c.z, c.w);
+          if (kTopNodes > 0 && cur < topCount) {
+            const float4 *T = ldsTop + (cur << 2);
+            a = T[0]; b = T[1]; c = T[2];
+            r = reinterpret_cast<const int4 *>(T)[3];
+            if (COUNT) ++tc.innerTop;
           } else {
-            dl = intersectAABBFinite(o, inv, a.x, a.y, a.z, a.w, b.x, b.y);
-            dr = intersectAABBFinite(o, inv, b.z, b.w, c.x, c.y, c.z, c.w);
+            const float4 *N = reinterpret_cast<const float4 *>(nodeBase + ((uint32_t)cur << 6));
+            a = N[0]; b = N[1]; c = N[2];
+            r = reinterpret_cast<const int4 *>(N)[3];
           }
-          // Near child first, right only if strictly nearer (src/acceleration/BVH.cpp:322-333); a child that cannot
-          // beat the closest hit any more is dropped here instead of at pop time.
           const float lim = RUNTIME_MODE ? __builtin_fminf(tBest, cullD) : tBest;
-          bool hl = dl < lim, hr = dr < lim;
-          bool both = hl && hr;
-          bool swap = both && dr < dl;
-          if (both) {
-            if (sp - lo == K) { spill[lo] = stackCol[(lo & (K - 1)) * BLOCK]; ++lo; }
-            stackCol[(sp & (K - 1)) * BLOCK] = make_uint2(__float_as_uint(swap ? dl : dr), (uint32_t)(swap ? r.x : r.y));
-            ++sp;
-          }
-          if (hl || hr) enter((hl && !swap) ? r.x : r.y);
-          else popNext();
+          if (waveExact) innerStep<true, K, BLOCK>(a, b, c, r, o, inv, lim, stackCol, spill, sp, lo, cur, pi, pe, op);  // wave-uniform: valid for every ray, just slower
+          else innerStep<false, K, BLOCK>(a, b, c, r, o, inv, lim, stackCol, spill, sp, lo, cur, pi, pe, op);
         }
         n = __popcll(__ballot(op == OP_INNER));
         if (canRefill && __popcll(__ballot(op >= OP_DONE)) >= kDoneBreak) break;
       } while (n > stayInner);
     } else {
       // ---------------------------------------------------------------- PRIM: one object of the current leaf
+      if (op == OP_PRIM && pe == 0) setLeaf(pi);  // leaves the INNER phase only noted
       int n = nPrim;
       do {
         if (op == OP_PRIM) {
           if (COUNT) { ++tc.prims; tc.primWaveIters += 1.0f / (float)n; }
           const float4 *P = reinterpret_cast<const float4 *>(primBase + (uint32_t)pi * 48u);
-          bool accepted = intersectPrim(S, P[0], P[1], P[2], pi, o, nd, tBest, primBest);
-          ++pi;
-          if (RUNTIME_MODE && accepted && mode != TRAV_CLOSEST) {
-            if (mode == TRAV_ANY) {
-              op = OP_DONE_EARLY;
-            } else {
-              // |point - info.point| < |center - point| with info.point = t * nd + origin (src/scene/Object.cpp:22-24)
-              V3 hp = tBest * nd + o;
-              if (magnitude(o - hp) < bulbDist) op = OP_DONE_EARLY;
-            }
-          }
-          if (op == OP_PRIM && pi == pe) popNext();
+          a = P[0]; b = P[1]; c = P[2];
+          RT_PRIM_STEP();
         }
         n = __popcll(__ballot(op == OP_PRIM));
       } while (n > stayPrim);
     }
   }
 }
+
+#undef RT_PRIM_STEP
 
 }  // namespace rtd

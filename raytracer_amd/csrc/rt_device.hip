@@ -49,18 +49,22 @@ constexpr int kStackLds = 8;      // stack entries per lane kept in LDS (8 B eac
 // Every group of fields that one kernel updates with atomics while others only read sits in a 128-byte line of its own:
 // a read of a line that thousands of wavefronts are adding to queues behind those adds.
 struct Ticket {
-  alignas(128) uint32_t next;  // next unclaimed queue index
+  alignas(128) uint32_t next;  // next unclaimed queue index of one segment
+};
+struct TicketSet {
+  Ticket seg[kQueueSegments];
 };
 struct Counts {
   alignas(128) uint32_t nActive;  // live paths of this bounce (written between kernels, and by k_raygen for fisheye)
   alignas(128) uint32_t nHit;     // appended by k_shade; {nHit, nNext} are added to as ONE 64-bit word
   uint32_t nNext;
-  Ticket ticket[3];               // [0] path extension, [1] light visibility, [2] trace-only kernels
+  TicketSet ticket[3];            // [0] path extension, [1] light visibility, [2] trace-only kernels
   alignas(128) unsigned long long skipPoint;  // visibility queries not traced (see ShadowSource), by query kind
   unsigned long long skipAny;
   unsigned long long planePoint, planeAny;    // visibility queries a plane answered before any BVH node was touched
   alignas(128) unsigned long long raysClosest, raysAny, samples, raysExtend, raysShadow;
   unsigned long long inner[2], prims[2], planes[2];  // [0] path extension, [1] light visibility
+  unsigned long long innerTop[2];
   float innerWaveIters[2], primWaveIters[2];
 };
 
@@ -75,6 +79,7 @@ struct PathBuf {
   uint32_t *qA, *qB, *qHit;
   Counts *counts;
   int32_t P, npix;
+  int32_t spp;  // samples per pixel in this pass; path slot = pixel position * spp + sample, so a pixel's samples are neighbours
 };
 static_assert(offsetof(Counts, nNext) == offsetof(Counts, nHit) + 4 && offsetof(Counts, nHit) % 8 == 0, "nHit/nNext form one 64-bit word");
 
@@ -117,14 +122,15 @@ template <bool COUNT>
 RT_DEV void flushCounters(Counts *c, const TravCounters &tc, int kind) {
   if (COUNT) {
     // wave reduction, then one atomic per wavefront and counter
-    unsigned long long a = tc.inner, b = tc.prims, p = tc.planes;
+    unsigned long long a = tc.inner, b = tc.prims, p = tc.planes, t = tc.innerTop;
     for (int off = 32; off > 0; off >>= 1) {
-      a += __shfl_down(a, off); b += __shfl_down(b, off); p += __shfl_down(p, off);
+      a += __shfl_down(a, off); b += __shfl_down(b, off); p += __shfl_down(p, off); t += __shfl_down(t, off);
     }
     float wi = tc.innerWaveIters, wp = tc.primWaveIters;
     for (int off = 32; off > 0; off >>= 1) { wi += __shfl_down(wi, off); wp += __shfl_down(wp, off); }
     if (__lane_id() == 0) {
       atomicAdd(&c->inner[kind], a); atomicAdd(&c->prims[kind], b); atomicAdd(&c->planes[kind], p);
+      atomicAdd(&c->innerTop[kind], t);
       atomicAdd(&c->innerWaveIters[kind], wi); atomicAdd(&c->primWaveIters[kind], wp);
     }
   }
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DevScene S, PathBuf B, const 
   bool valid = i < (int64_t)B.npix * sppThis;
   bool alive = false;
   if (valid) {
-    int32_t p = (int32_t)(i % B.npix), s = (int32_t)(i / B.npix);
+    int32_t p = (int32_t)(i / sppThis), s = (int32_t)(i % sppThis);
     int32_t pixel = pixList[p];
     int32_t x = pixel % S.width, y = pixel / S.width;
     Rng rng = rngInit(seed, (uint32_t)pixel, (uint32_t)(sampleBase + s), 0u);
@@ -206,14 +212,18 @@ __global__ RT_TRAV_ATTR void k_extend(DevScene S, PathBuf B, const uint32_t *que
   __shared__ uint2 ldsStack[kStackLds * kBlock];
 
   __shared__ uint32_t ldsPool[(kBlock / 64) * kPoolFields * kPoolSlots];
-  TravCounters tc = {0, 0, 0, 0, 0, 0.0f, 0.0f};
+  __shared__ float4 ldsTop[4 * (kTopNodes > 0 ? kTopNodes : 1)];
+  TravCounters tc{};
   ExtendSource src{B, queue};
-  traverseQueue<ExtendSource, false, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[0].next, ldsStack, ldsPool, tc);
+  traverseQueue<ExtendSource, false, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[0].seg[0].next, ldsStack, ldsPool, ldsTop, tc);
   flushCounters<COUNT>(B.counts, tc, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------- k_shade
-__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, PathBuf B, const uint32_t *queue, uint32_t *queueNext,
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 5
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, 8))) void k_shade(DevScene S, PathBuf B, const uint32_t *queue, uint32_t *queueNext,
                                                   int32_t bounce, const int32_t *pixList, int32_t sampleBase, uint32_t seed) {
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   bool isHit = false, continues = false;
@@ -226,8 +236,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, PathBuf B, const u
     int32_t prim = B.hitPrim[slot];
     float t = B.hitT[slot];
     // the path's random stream is a function of its pixel and sample index; only the draw count is stored
-    const uint32_t sampleInPass = slot / (uint32_t)B.npix;
-    Rng rng = rngInit(seed, (uint32_t)pixList[slot - sampleInPass * (uint32_t)B.npix], (uint32_t)sampleBase + sampleInPass, B.rng[slot]);
+    const uint32_t pixPos = slot / (uint32_t)B.spp, sampleInPass = slot - pixPos * (uint32_t)B.spp;
+    Rng rng = rngInit(seed, (uint32_t)pixList[pixPos], (uint32_t)sampleBase + sampleInPass, B.rng[slot]);
     float4 beta4 = B.beta[slot];
     V3 o = v3(o4.x, o4.y, o4.z), d = v3(d4.x, d4.y, d4.z);
     const bool onObject = prim >= 0 && prim < S.numPrims;
@@ -239,12 +249,12 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, PathBuf B, const u
       const int64_t pc = onObject ? prim : 0;
       const float4 *P = S.primHit + 3 * pc;
       od.a = P[0]; od.b = P[1]; od.c = P[2];
-      const float *np = S.primNormals + 9 * pc;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) nn[k] = np[k];
-      od.material = S.primMaterial[pc];
-      od.color = S.primColor[pc];
-      od.texture = S.primTexture[pc];
+      const float4 *Q = S.primShade + 4 * pc;
+      const float4 q0 = Q[0], q1 = Q[1], q2 = Q[2], q3 = Q[3];
+      nn[0] = q0.x; nn[1] = q0.y; nn[2] = q0.z; nn[3] = q0.w; nn[4] = q1.x; nn[5] = q1.y; nn[6] = q1.z; nn[7] = q1.w; nn[8] = q2.x;
+      od.color = make_float4(q2.y, q2.z, q2.w, q3.x);
+      od.material = __float_as_int(q3.y);
+      od.texture = __float_as_int(q3.z);
     }
     if (prim < 0) {
       // miss: add every light's emittedLight(direction) (raytracer.cpp:217-223); only environment lights emit
@@ -385,9 +395,10 @@ template <bool COUNT>
 __global__ RT_TRAV_ATTR void k_shadow(DevScene S, PathBuf B) {
   __shared__ uint2 ldsStack[kStackLds * kBlock];
   __shared__ uint32_t ldsPool[(kBlock / 64) * kPoolFields * kPoolSlots];
-  TravCounters tc = {0, 0, 0, 0, 0, 0.0f, 0.0f};
+  __shared__ float4 ldsTop[4 * (kTopNodes > 0 ? kTopNodes : 1)];
+  TravCounters tc{};
   ShadowSource src{S, B, B.counts->nHit};
-  traverseQueue<ShadowSource, true, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[1].next, ldsStack, ldsPool, tc);
+  traverseQueue<ShadowSource, true, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[1].seg[0].next, ldsStack, ldsPool, ldsTop, tc);
   flushCounters<COUNT>(B.counts, tc, 1);
   uint32_t sp = src.skippedPoint, sa = src.skippedAny, pp = tc.planeAnsweredPoint, pa = tc.planeAnsweredAny;
   for (int off = 32; off > 0; off >>= 1) {
@@ -423,12 +434,12 @@ __global__ void k_advance(PathBuf B, int32_t numPointLights, int32_t numAnyLight
   c->nActive = c->nNext;
   c->nNext = 0;
   c->nHit = 0;
-  c->ticket[0].next = 0; c->ticket[1].next = 0;
+  for (int g = 0; g < kQueueSegments; ++g) { c->ticket[0].seg[g].next = 0; c->ticket[1].seg[g].next = 0; }
 }
 __global__ void k_begin_pass(PathBuf B, uint32_t nActive) {
   Counts *c = B.counts;
   c->nActive = nActive; c->nNext = 0; c->nHit = 0;
-  c->ticket[0].next = 0; c->ticket[1].next = 0;
+  for (int g = 0; g < kQueueSegments; ++g) { c->ticket[0].seg[g].next = 0; c->ticket[1].seg[g].next = 0; }
 }
 __global__ void k_count_samples(PathBuf B, unsigned long long n) { B.counts->samples += n; }  // rejected fisheye samples count too
 
@@ -439,7 +450,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PathBuf B, float4 *pixSum
   RGBA avg = rgba(pixSum[p]);
   int hits = pixHits[p];
   for (int s = 0; s < sppThis; ++s) {
-    RGBA color = rgba(B.L[(int64_t)s * B.npix + p]);
+    RGBA color = rgba(B.L[(int64_t)p * sppThis + s]);
     if (hasNaN(color) == false && color.a != 0) {
       addAssign(avg, color);
       ++hits;
@@ -503,7 +514,7 @@ __global__ __launch_bounds__(kBlock) void k_srgb8(const float4 *fb, uchar4 *out,
 
 // ---------------------------------------------------------------------------------------------------- trace-only kernels
 RT_DEV int32_t reportedId(const DevScene &S, int32_t prim) {
-  return prim < 0 ? -1 : (prim < S.numPrims ? S.primOrigIndex[prim] : prim);
+  return prim < 0 ? -1 : (prim < S.numPrims ? __float_as_int(S.primShade[4 * (int64_t)prim + 3].w) : prim);
 }
 
 struct PrimarySource {
@@ -541,9 +552,10 @@ __global__ __launch_bounds__(kBlock) void k_trace_primary(DevScene S, int32_t x0
                                                           int32_t *outPrim, float *outT, uint32_t *ticket) {
   __shared__ uint2 ldsStack[kStackLds * kBlock];
   __shared__ uint32_t ldsPool[(kBlock / 64) * kPoolFields * kPoolSlots];
-  TravCounters tc = {0, 0, 0, 0, 0, 0.0f, 0.0f};
+  __shared__ float4 ldsTop[4 * (kTopNodes > 0 ? kTopNodes : 1)];
+  TravCounters tc{};
   PrimarySource src{S, x0, y0, w, h, outPrim, outT};
-  traverseQueue<PrimarySource, false, false, kStackLds, kBlock>(S, src, ticket, ldsStack, ldsPool, tc);
+  traverseQueue<PrimarySource, false, false, kStackLds, kBlock>(S, src, ticket, ldsStack, ldsPool, ldsTop, tc);
 }
 
 template <bool ANY>
@@ -579,8 +591,9 @@ struct RaysSource {
           V3 q = point - p1;
           float b2 = dot(e1, q), b3 = dot(e2, q);
           float b1 = 1.0f - b3 - b2;
-          const float *nn = S.primNormals + 9 * (int64_t)hr.prim;
-          normal = normalized(v3(nn) * b1 + v3(nn + 3) * b2 + v3(nn + 6) * b3);
+          const float4 *Q = S.primShade + 4 * (int64_t)hr.prim;
+          const float4 q0 = Q[0], q1 = Q[1], q2 = Q[2];
+          normal = normalized(v3(q0.x, q0.y, q0.z) * b1 + v3(q0.w, q1.x, q1.y) * b2 + v3(q1.z, q1.w, q2.x) * b3);
         }
       }
     }
@@ -595,9 +608,10 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene S, int64_t n, co
                                                        uint8_t *outOccluded, uint32_t *ticket) {
   __shared__ uint2 ldsStack[kStackLds * kBlock];
   __shared__ uint32_t ldsPool[(kBlock / 64) * kPoolFields * kPoolSlots];
-  TravCounters tc = {0, 0, 0, 0, 0, 0.0f, 0.0f};
+  __shared__ float4 ldsTop[4 * (kTopNodes > 0 ? kTopNodes : 1)];
+  TravCounters tc{};
   RaysSource<ANY> src{S, n, origins, directions, outPrim, outT, outPoint, outNormal, outOccluded};
-  traverseQueue<RaysSource<ANY>, ANY, false, kStackLds, kBlock>(S, src, ticket, ldsStack, ldsPool, tc);
+  traverseQueue<RaysSource<ANY>, ANY, false, kStackLds, kBlock>(S, src, ticket, ldsStack, ldsPool, ldsTop, tc);
 }
 
 // ---------------------------------------------------------------------------------------------------- host side
@@ -791,6 +805,25 @@ int buildScene(RtScene *s, const RtSceneDesc *d) {
   int32_t numInner = 0;
   for (int32_t i = 0; i < d->numNodes; ++i)
     if (d->nodes[i].numObjects <= 0) innerOrdinal[i] = numInner++;
+  // The first kTopNodes inner nodes in breadth-first order come first (the kernels keep them in LDS); the rest keep
+  // their pre-order among themselves.
+  int32_t numTop = 0;
+  if (kTopNodes > 0 && numInner > 0) {
+    std::vector<int32_t> isTop(d->numNodes, 0), bfs;
+    bfs.push_back(0);
+    for (size_t head = 0; head < bfs.size() && bfs.size() < (size_t)kTopNodes; ++head) {
+      int32_t node = bfs[head];
+      for (int32_t child : {node + 1, d->nodes[node].rightOrStart})
+        if (d->nodes[child].numObjects <= 0) bfs.push_back(child);
+    }
+    numTop = (int32_t)std::min<size_t>(bfs.size(), (size_t)kTopNodes);
+    for (int32_t k = 0; k < numTop; ++k) isTop[bfs[k]] = 1;
+    int32_t next = numTop;
+    for (int32_t i = 0; i < d->numNodes; ++i)
+      if (innerOrdinal[i] >= 0 && !isTop[i]) innerOrdinal[i] = next++;
+    for (int32_t k = 0; k < numTop; ++k) innerOrdinal[bfs[k]] = k;
+  }
+  dev.numTopNodes = numTop;
   std::vector<BigLeaf> bigLeaves;
   auto childRef = [&](int32_t node) -> int32_t {
     const RtBvhNode &n = d->nodes[node];
@@ -866,12 +899,20 @@ int buildScene(RtScene *s, const RtSceneDesc *d) {
   if ((rc = upload(s, nodes.data(), nodes.size(), &dev.nodes))) return rc;
   if ((rc = upload(s, primHit.data(), primHit.size(), &dev.primHit))) return rc;
   if ((rc = upload(s, bigLeaves.data(), bigLeaves.size(), &dev.bigLeaves))) return rc;
-  if ((rc = upload(s, d->primNormals, n * 9, &dev.primNormals))) return rc;
+  {
+    std::vector<float4> shade(n * 4);
+    for (size_t i = 0; i < n; ++i) {
+      const float *nn = d->primNormals + i * 9, *col = d->primColor + i * 4;
+      char *rec = reinterpret_cast<char *>(&shade[i * 4]);  // copied as bytes: three of the words are integers
+      std::memcpy(rec, nn, 36);
+      std::memcpy(rec + 36, col, 16);
+      std::memcpy(rec + 52, &d->primMaterial[i], 4);
+      std::memcpy(rec + 56, &d->primTexture[i], 4);
+      std::memcpy(rec + 60, &d->primOrigIndex[i], 4);
+    }
+    if ((rc = upload(s, shade.data(), shade.size(), &dev.primShade))) return rc;  // hipMalloc: 256-byte aligned
+  }
   if (d->primTexCoords) { if ((rc = upload(s, d->primTexCoords, n * 9, &dev.primTexCoords))) return rc; }
-  if ((rc = upload(s, reinterpret_cast<const float4 *>(d->primColor), n, &dev.primColor))) return rc;
-  if ((rc = upload(s, d->primMaterial, n, &dev.primMaterial))) return rc;
-  if ((rc = upload(s, d->primTexture, n, &dev.primTexture))) return rc;
-  if ((rc = upload(s, d->primOrigIndex, n, &dev.primOrigIndex))) return rc;
   // ---- planes, materials, lights, textures
   std::vector<DevPlane> planes(d->numPlanes);
   for (int32_t i = 0; i < d->numPlanes; ++i) {
@@ -1036,7 +1077,7 @@ inline unsigned persistentGrid(const RtScene *s, int64_t n) {
 // copy at its own address from the moment the code object is loaded until the process ends. Host code never uses the
 // array's name as an address; it asks the runtime for the device address once per device (resolveStaticScratch).
 constexpr int64_t kStaticTraceMaxPixels = (int64_t)1 << 22;  // 4 Mi pixels (2048 x 2048): 32 MiB of staging
-constexpr size_t kStaticTicketBytes = 256;
+constexpr size_t kStaticTicketBytes = sizeof(Ticket) * kQueueSegments;  // 1 KiB
 constexpr size_t kStaticScratchBytes = kStaticTicketBytes + (size_t)kStaticTraceMaxPixels * 8;
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 
@@ -1177,9 +1218,9 @@ int rt_trace_primary(RtScene *s, int32_t x0, int32_t y0, int32_t w, int32_t h, i
   if ((rc = ensureWorkEvents(s))) return rc;
   int32_t *dPrim = static_cast<int32_t *>(s->work);
   float *dT = reinterpret_cast<float *>(static_cast<char *>(s->work) + alignUp256((size_t)n * 4));
-  HIP_TRY(hipMemsetAsync(&s->counts->ticket[2].next, 0, sizeof(uint32_t), s->stream));
+  HIP_TRY(hipMemsetAsync(&s->counts->ticket[2], 0, sizeof(TicketSet), s->stream));
   HIP_TRY(hipEventRecord(s->workEvA, s->stream));
-  launchTracePrimary(s, x0, y0, w, h, dPrim, dT, &s->counts->ticket[2].next);
+  launchTracePrimary(s, x0, y0, w, h, dPrim, dT, &s->counts->ticket[2].seg[0].next);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->workEvB, s->stream));
   HIP_TRY(hipMemcpyAsync(primId, dPrim, n * 4, hipMemcpyDefault, s->stream));
@@ -1237,10 +1278,10 @@ static int traceRays(RtScene *s, bool any, int64_t n, const float *origins, cons
   float *dT = (!any && t) ? reinterpret_cast<float *>(base + oT) : nullptr;
   float *dP = (!any && point) ? reinterpret_cast<float *>(base + oP) : nullptr;
   float *dN = (!any && normal) ? reinterpret_cast<float *>(base + oN) : nullptr;
-  uint32_t *ticket = &s->counts->ticket[2].next;
+  uint32_t *ticket = &s->counts->ticket[2].seg[0].next;
   HIP_TRY(hipMemcpyAsync(dO, origins, n * 12, hipMemcpyDefault, s->stream));
   HIP_TRY(hipMemcpyAsync(dD, directions, n * 12, hipMemcpyDefault, s->stream));
-  HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(uint32_t), s->stream));
+  HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(TicketSet), s->stream));
   HIP_TRY(hipEventRecord(s->workEvA, s->stream));
   if (any) k_trace_rays<true><<<persistentGrid(s, n), kBlock, 0, s->stream>>>(s->dev, n, dO, dD, nullptr, nullptr, nullptr, nullptr, dOcc, ticket);
   else k_trace_rays<false><<<persistentGrid(s, n), kBlock, 0, s->stream>>>(s->dev, n, dO, dD, dPrim, dT, dP, dN, nullptr, ticket);
@@ -1338,6 +1379,7 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
   for (int sBase = 0; npix > 0 && sBase < S.numRays; sBase += sppPass, ++passes) {
     int sppThis = std::min(sppPass, S.numRays - sBase);
     int64_t n = npix * sppThis;
+    B.spp = sppThis;
     unsigned grid = gridFor(n);
     k_begin_pass<<<1, 1, 0, st>>>(B, S.cameraMode == 1 ? 0u : (uint32_t)n);
     if ((rc = beginEvent(s, CAT_RAYGEN, timing))) return rc;
@@ -1392,6 +1434,7 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
     stats->raysSkipped = hc.skipPoint + hc.skipAny + hc.planePoint + hc.planeAny;
     stats->raysPlaneAnswered = hc.planePoint + hc.planeAny;
     stats->innerExpansions = hc.inner[0] + hc.inner[1];
+    stats->innerTopExpansions = hc.innerTop[0] + hc.innerTop[1];
     stats->primTests = hc.prims[0] + hc.prims[1];
     stats->planeTests = hc.planes[0] + hc.planes[1];
     stats->raysExtend = hc.raysExtend; stats->raysShadow = hc.raysShadow - hc.skipPoint - hc.skipAny - hc.planePoint - hc.planeAny;
