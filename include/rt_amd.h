@@ -164,9 +164,6 @@ typedef struct RtStats {
    * raysShadow, which count traversed queries only */
   uint64_t raysSkipped;
   uint64_t raysPlaneAnswered;
-  /* only with collectCounters: inner-node expansions (of innerExpansions) whose record came from the copy of the
-   * tree top that every workgroup keeps in LDS instead of from the vector cache */
-  uint64_t innerTopExpansions;
 } RtStats;
 
 typedef struct RtScene RtScene;

@@ -2,9 +2,8 @@
 //
 //   nodes      one 64-byte record per INNER node of the reference's BVH (src/acceleration/BVH.h:49-61): the boxes of
 //              both children plus a packed reference to each, so that one inner step is one 64-byte fetch instead of
-//              the two 32-byte fetches (left at idx+1, right far away) the pre-order array needs. The first
-//              numTopNodes records are the top of the tree in breadth-first order (every workgroup copies them into
-//              LDS); the others follow in pre-order, which keeps a subtree contiguous. Four float4 per record:
+//              the two 32-byte fetches (left at idx+1, right far away) the pre-order array needs. Inner records are
+//              numbered in pre-order, which keeps a subtree contiguous. Four float4 per record:
 //                [0] lmin.xyz lmax.x   [1] lmax.yz rmin.xy   [2] rmin.z rmax.xyz   [3] leftRef rightRef 0 0 (as ints)
 //   primHit    48 bytes per BVH object, in BVH order, three float4:
 //                triangle: p1.xyz n.x | n.yz e1.xy | e1.z e2.xyz        (src/scene/Object.h:162-165)
@@ -72,7 +71,6 @@ struct DevScene {
   const float4 *nodes;
   const float4 *primHit;
   const BigLeaf *bigLeaves;
-  int32_t numTopNodes;  // inner records 0 .. numTopNodes-1 are the top of the tree in breadth-first order (kept in LDS by the kernels)
   int32_t rootRef;  // packed reference of the root; 0x7fffffff = no BVH (no objects)
   float rootMin[3], rootMax[3];
   int32_t numPrims;

@@ -42,7 +42,6 @@ RT_DEV float intersectAABB(V3 o, V3 inv, float mnx, float mny, float mnz, float 
 struct TravCounters {
   uint32_t planeAnsweredPoint, planeAnsweredAny;  // always counted: visibility queries the planes answered (no BVH traversal)
   uint32_t inner, prims, planes;
-  uint32_t innerTop;  // inner-node expansions served from the LDS copy of the tree top
   // wave-level iteration counts (each active lane adds 1/active, so the wave sums to 1 per iteration): with `inner`
   // and `prims` they give the fraction of the 64 lanes doing useful work in the two hot loops
   float innerWaveIters, primWaveIters;
@@ -149,24 +148,13 @@ enum { TRAV_CLOSEST = 0, TRAV_ANY = 1, TRAV_POINT_LIGHT = 2, TRAV_SKIP = 3 };
 #ifndef RT_DONE_BREAK
 #define RT_DONE_BREAK 12
 #endif
-#ifndef RT_MERGED
-#define RT_MERGED 1
-#endif
-#ifndef RT_MERGED_BREAK
-#define RT_MERGED_BREAK 8
-#endif
 #ifndef RT_TAKE_MIN
 #define RT_TAKE_MIN 8
 #endif
-#ifndef RT_TOP_NODES
-#define RT_TOP_NODES 0
-#endif
-constexpr int kTopNodes = RT_TOP_NODES;      // inner records of the tree top every workgroup keeps in LDS (0 = none)
 constexpr int kPoolSlots = RT_POOL_SLOTS;    // prepared queries a wavefront keeps in LDS (power of two)
 constexpr int kPoolFields = 13;   // dwords per prepared query
 constexpr int kPoolLow = RT_POOL_LOW;      // prepare more queries once at most this many are left
 constexpr int kDoneBreak = RT_DONE_BREAK;  // a phase loop ends early once this many lanes have finished their query
-constexpr int kMergedBreak = RT_MERGED_BREAK;  // merged stepping stops for a service step once this many lanes have no work
 constexpr int kTakeMin = RT_TAKE_MIN;      // lanes without work (done or idle) before results are written and new queries taken
 
 // Limits the host checks before a scene reaches the GPU (rt_scene_create): node and object records are addressed
@@ -211,11 +199,8 @@ constexpr int kMaxTreeDepth = kMaxStack;
 //   uint32_t fetch(uint32_t idx, V3 &o, V3 &d, int &mode, float &bulbDist) load query idx, return a tag for store()
 //   void store(uint32_t tag, HitRec hit, bool occluded, V3 o, V3 nd)       deliver its result
 //
-// LDS the caller provides: ldsStack = K * BLOCK uint2 (stack columns), ldsPool = (BLOCK / 64) * kPoolFields * kPoolSlots dwords,
-// ldsTop = 4 * max(kTopNodes, 1) float4. The inner records 0 .. S.numTopNodes-1 (the top of the tree in breadth-first order,
-// which every query walks through) are copied into ldsTop once per workgroup: the vector cache serves a scattered
-// 16-byte access per lane at ~1.2-1.5 per clock and CU and is the unit these kernels saturate, LDS serves about twice as
-// many and runs beside it. Must be called by every thread of the workgroup (it synchronises once, before the first query).
+// LDS the caller provides: ldsStack = K * BLOCK uint2 (stack columns), ldsPool = (BLOCK / 64) * kPoolFields * kPoolSlots dwords.
+
 // Lane states of the traversal engine (see traverseQueue).
 enum { OP_IDLE = 0, OP_INNER = 1, OP_PRIM = 2, OP_DONE = 3, OP_DONE_EARLY = 4 };
 
@@ -281,12 +266,7 @@ RT_DEV void innerStep(float4 a, float4 b, float4 c, int4 r, V3 o, V3 inv, float 
   } while (0)
 
 template <class Source, bool RUNTIME_MODE, bool COUNT, int K, int BLOCK>
-RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint2 *ldsStack, uint32_t *ldsPool, float4 *ldsTop, TravCounters &tc) {
-  const int32_t topCount = kTopNodes > 0 ? S.numTopNodes : 0;
-  if (kTopNodes > 0) {
-    for (int i = threadIdx.x; i < topCount * 4; i += BLOCK) ldsTop[i] = S.nodes[i];
-    __syncthreads();
-  }
+RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint2 *ldsStack, uint32_t *ldsPool, TravCounters &tc) {
   static_assert((K & (K - 1)) == 0, "K must be a power of two");
   static_assert((kPoolSlots & (kPoolSlots - 1)) == 0 && kPoolSlots <= 64, "pool size");
   const uint32_t total = src.total();
@@ -529,53 +509,15 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
     // measured best on MI355X (a PRIM phase is short, so running it almost dry costs little and saves votes)
     const int stayInner = ((nInner + nPrim) * RT_STAY_INNER) >> 3, stayPrim = ((nInner + nPrim) * RT_STAY_PRIM) >> 3;
     const bool canRefill = poolCount > 0 || !exhausted;  // a finished lane can be given a new query at the next vote
-#if RT_MERGED
-    // ------------------------------------------------------------------ one step for every lane that has work
-    // The kernels are bound by the latency of the scattered record fetches (throughput follows the number of wavefronts
-    // in flight, the vector ALU is busy about half of the time), so what counts is the number of fetch round trips per
-    // query: every lane with work fetches its record — a node or an object, same registers — in the same round trip,
-    // and then each kind runs its own code.
-    {
-      int nWork = nInner + nPrim;
-      do {
-        const bool isInner = op == OP_INNER, isPrim = op == OP_PRIM;
-        if (isPrim && pe == 0) setLeaf(pi);  // a leaf an INNER step only noted
-        if (isInner || isPrim) {
-          const float4 *R = reinterpret_cast<const float4 *>(isInner ? nodeBase + ((uint32_t)cur << 6) : primBase + (uint32_t)pi * 48u);
-          a = R[0]; b = R[1]; c = R[2];
-          if (isInner) r = reinterpret_cast<const int4 *>(R)[3];
-        }
-        if (isInner) {
-          if (COUNT) { ++tc.inner; tc.innerWaveIters += 1.0f / (float)nWork; }
-          const float lim = RUNTIME_MODE ? __builtin_fminf(tBest, cullD) : tBest;
-          if (waveExact) innerStep<true, K, BLOCK>(a, b, c, r, o, inv, lim, stackCol, spill, sp, lo, cur, pi, pe, op);
-          else innerStep<false, K, BLOCK>(a, b, c, r, o, inv, lim, stackCol, spill, sp, lo, cur, pi, pe, op);
-        }
-        if (isPrim) {
-          if (COUNT) { ++tc.prims; tc.primWaveIters += 1.0f / (float)nWork; }
-          RT_PRIM_STEP();
-        }
-        nWork = __popcll(__ballot(op == OP_INNER || op == OP_PRIM));
-      } while (nWork > 0 && !(canRefill && 64 - nWork >= kMergedBreak));
-    }
-    continue;
-#endif
     if (nInner >= nPrim) {
       // ---------------------------------------------------------------- INNER: both child boxes of the current node
       int n = nInner;
       do {
         if (op == OP_INNER) {
           if (COUNT) { ++tc.inner; tc.innerWaveIters += 1.0f / (float)n; }
-          if (kTopNodes > 0 && cur < topCount) {
-            const float4 *T = ldsTop + (cur << 2);
-            a = T[0]; b = T[1]; c = T[2];
-            r = reinterpret_cast<const int4 *>(T)[3];
-            if (COUNT) ++tc.innerTop;
-          } else {
-            const float4 *N = reinterpret_cast<const float4 *>(nodeBase + ((uint32_t)cur << 6));
-            a = N[0]; b = N[1]; c = N[2];
-            r = reinterpret_cast<const int4 *>(N)[3];
-          }
+          const float4 *N = reinterpret_cast<const float4 *>(nodeBase + ((uint32_t)cur << 6));
+          a = N[0]; b = N[1]; c = N[2];
+          r = reinterpret_cast<const int4 *>(N)[3];
           const float lim = RUNTIME_MODE ? __builtin_fminf(tBest, cullD) : tBest;
           if (waveExact) innerStep<true, K, BLOCK>(a, b, c, r, o, inv, lim, stackCol, spill, sp, lo, cur, pi, pe, op);  // wave-uniform: valid for every ray, just slower
           else innerStep<false, K, BLOCK>(a, b, c, r, o, inv, lim, stackCol, spill, sp, lo, cur, pi, pe, op);

@@ -64,7 +64,6 @@ struct Counts {
   unsigned long long planePoint, planeAny;    // visibility queries a plane answered before any BVH node was touched
   alignas(128) unsigned long long raysClosest, raysAny, samples, raysExtend, raysShadow;
   unsigned long long inner[2], prims[2], planes[2];  // [0] path extension, [1] light visibility
-  unsigned long long innerTop[2];
   float innerWaveIters[2], primWaveIters[2];
 };
 
@@ -122,15 +121,14 @@ template <bool COUNT>
 RT_DEV void flushCounters(Counts *c, const TravCounters &tc, int kind) {
   if (COUNT) {
     // wave reduction, then one atomic per wavefront and counter
-    unsigned long long a = tc.inner, b = tc.prims, p = tc.planes, t = tc.innerTop;
+    unsigned long long a = tc.inner, b = tc.prims, p = tc.planes;
     for (int off = 32; off > 0; off >>= 1) {
-      a += __shfl_down(a, off); b += __shfl_down(b, off); p += __shfl_down(p, off); t += __shfl_down(t, off);
+      a += __shfl_down(a, off); b += __shfl_down(b, off); p += __shfl_down(p, off);
     }
     float wi = tc.innerWaveIters, wp = tc.primWaveIters;
     for (int off = 32; off > 0; off >>= 1) { wi += __shfl_down(wi, off); wp += __shfl_down(wp, off); }
     if (__lane_id() == 0) {
       atomicAdd(&c->inner[kind], a); atomicAdd(&c->prims[kind], b); atomicAdd(&c->planes[kind], p);
-      atomicAdd(&c->innerTop[kind], t);
       atomicAdd(&c->innerWaveIters[kind], wi); atomicAdd(&c->primWaveIters[kind], wp);
     }
   }
@@ -212,10 +210,9 @@ __global__ RT_TRAV_ATTR void k_extend(DevScene S, PathBuf B, const uint32_t *que
   __shared__ uint2 ldsStack[kStackLds * kBlock];
 
   __shared__ uint32_t ldsPool[(kBlock / 64) * kPoolFields * kPoolSlots];
-  __shared__ float4 ldsTop[4 * (kTopNodes > 0 ? kTopNodes : 1)];
   TravCounters tc{};
   ExtendSource src{B, queue};
-  traverseQueue<ExtendSource, false, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[0].seg[0].next, ldsStack, ldsPool, ldsTop, tc);
+  traverseQueue<ExtendSource, false, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[0].seg[0].next, ldsStack, ldsPool, tc);
   flushCounters<COUNT>(B.counts, tc, 0);
 }
 
@@ -395,10 +392,9 @@ template <bool COUNT>
 __global__ RT_TRAV_ATTR void k_shadow(DevScene S, PathBuf B) {
   __shared__ uint2 ldsStack[kStackLds * kBlock];
   __shared__ uint32_t ldsPool[(kBlock / 64) * kPoolFields * kPoolSlots];
-  __shared__ float4 ldsTop[4 * (kTopNodes > 0 ? kTopNodes : 1)];
   TravCounters tc{};
   ShadowSource src{S, B, B.counts->nHit};
-  traverseQueue<ShadowSource, true, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[1].seg[0].next, ldsStack, ldsPool, ldsTop, tc);
+  traverseQueue<ShadowSource, true, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[1].seg[0].next, ldsStack, ldsPool, tc);
   flushCounters<COUNT>(B.counts, tc, 1);
   uint32_t sp = src.skippedPoint, sa = src.skippedAny, pp = tc.planeAnsweredPoint, pa = tc.planeAnsweredAny;
   for (int off = 32; off > 0; off >>= 1) {
@@ -552,10 +548,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_primary(DevScene S, int32_t x0
                                                           int32_t *outPrim, float *outT, uint32_t *ticket) {
   __shared__ uint2 ldsStack[kStackLds * kBlock];
   __shared__ uint32_t ldsPool[(kBlock / 64) * kPoolFields * kPoolSlots];
-  __shared__ float4 ldsTop[4 * (kTopNodes > 0 ? kTopNodes : 1)];
   TravCounters tc{};
   PrimarySource src{S, x0, y0, w, h, outPrim, outT};
-  traverseQueue<PrimarySource, false, false, kStackLds, kBlock>(S, src, ticket, ldsStack, ldsPool, ldsTop, tc);
+  traverseQueue<PrimarySource, false, false, kStackLds, kBlock>(S, src, ticket, ldsStack, ldsPool, tc);
 }
 
 template <bool ANY>
@@ -608,10 +603,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene S, int64_t n, co
                                                        uint8_t *outOccluded, uint32_t *ticket) {
   __shared__ uint2 ldsStack[kStackLds * kBlock];
   __shared__ uint32_t ldsPool[(kBlock / 64) * kPoolFields * kPoolSlots];
-  __shared__ float4 ldsTop[4 * (kTopNodes > 0 ? kTopNodes : 1)];
   TravCounters tc{};
   RaysSource<ANY> src{S, n, origins, directions, outPrim, outT, outPoint, outNormal, outOccluded};
-  traverseQueue<RaysSource<ANY>, ANY, false, kStackLds, kBlock>(S, src, ticket, ldsStack, ldsPool, ldsTop, tc);
+  traverseQueue<RaysSource<ANY>, ANY, false, kStackLds, kBlock>(S, src, ticket, ldsStack, ldsPool, tc);
 }
 
 // ---------------------------------------------------------------------------------------------------- host side
@@ -805,25 +799,6 @@ int buildScene(RtScene *s, const RtSceneDesc *d) {
   int32_t numInner = 0;
   for (int32_t i = 0; i < d->numNodes; ++i)
     if (d->nodes[i].numObjects <= 0) innerOrdinal[i] = numInner++;
-  // The first kTopNodes inner nodes in breadth-first order come first (the kernels keep them in LDS); the rest keep
-  // their pre-order among themselves.
-  int32_t numTop = 0;
-  if (kTopNodes > 0 && numInner > 0) {
-    std::vector<int32_t> isTop(d->numNodes, 0), bfs;
-    bfs.push_back(0);
-    for (size_t head = 0; head < bfs.size() && bfs.size() < (size_t)kTopNodes; ++head) {
-      int32_t node = bfs[head];
-      for (int32_t child : {node + 1, d->nodes[node].rightOrStart})
-        if (d->nodes[child].numObjects <= 0) bfs.push_back(child);
-    }
-    numTop = (int32_t)std::min<size_t>(bfs.size(), (size_t)kTopNodes);
-    for (int32_t k = 0; k < numTop; ++k) isTop[bfs[k]] = 1;
-    int32_t next = numTop;
-    for (int32_t i = 0; i < d->numNodes; ++i)
-      if (innerOrdinal[i] >= 0 && !isTop[i]) innerOrdinal[i] = next++;
-    for (int32_t k = 0; k < numTop; ++k) innerOrdinal[bfs[k]] = k;
-  }
-  dev.numTopNodes = numTop;
   std::vector<BigLeaf> bigLeaves;
   auto childRef = [&](int32_t node) -> int32_t {
     const RtBvhNode &n = d->nodes[node];
@@ -1434,7 +1409,6 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
     stats->raysSkipped = hc.skipPoint + hc.skipAny + hc.planePoint + hc.planeAny;
     stats->raysPlaneAnswered = hc.planePoint + hc.planeAny;
     stats->innerExpansions = hc.inner[0] + hc.inner[1];
-    stats->innerTopExpansions = hc.innerTop[0] + hc.innerTop[1];
     stats->primTests = hc.prims[0] + hc.prims[1];
     stats->planeTests = hc.planes[0] + hc.planes[1];
     stats->raysExtend = hc.raysExtend; stats->raysShadow = hc.raysShadow - hc.skipPoint - hc.skipAny - hc.planePoint - hc.planeAny;
