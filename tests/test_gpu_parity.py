@@ -5,13 +5,15 @@ Bars: primary hits and arbitrary closest/any queries are BIT-EXACT (ids, bits of
 shaded images at matched counter-RNG streams: PSNR >= 40 dB over r,g,b (the tolerance north_star states), plus a
 bound on the fraction of pixels that differ visibly; tile partitions recombine bit-exactly."""
 import hashlib
+import os
+import subprocess
 import zlib
 
 import numpy as np
 import pytest
 
 from raytracer_amd import capi
-from tests.conftest import SMALL_SCENES, psnr
+from tests.conftest import REPO, SMALL_SCENES, psnr
 from tests.oracle_binding import oracle_scene
 
 pytestmark = pytest.mark.gpu
@@ -276,6 +278,22 @@ def test_device_to_device_gather_of_tile_partitions(scenes):
     finally:
         for p in parts:
             p.close()
+
+
+REF_BINDING = os.path.join(REPO, "oracle", "_ref", "ref_binding")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BINDING), reason="oracle/_ref/ref_binding was not built (it needs the reference sources)")
+@pytest.mark.parametrize("name", ["materials", "mesh1k_gi", "readme_small"])
+def test_reference_side_binding_drives_the_hip_library(name, scene_path):
+    """The compiled reference-side binding (oracle/ref_binding.cpp: the reference's own Scene -> RtSceneDesc -> C ABI)
+    loaded with the HIP library: every primary hit must equal Scene::findClosestObject of the compiled reference, id and
+    t bits. The program contains the reference's code, built in the build container; nothing is read from the reference
+    at run time."""
+    path = scene_path(name)
+    r = subprocess.run([REF_BINDING, os.path.basename(path), os.path.join(REPO, "raytracer_amd", "libraytracer_amd.so"), "rt_"],
+                       cwd=os.path.dirname(path), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "BINDING OK" in r.stdout and ", 0 mismatches" in r.stdout, r.stdout[-600:] + r.stderr[-600:]
 
 
 def test_counters_match_oracle_work(scenes):

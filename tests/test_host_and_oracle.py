@@ -259,6 +259,23 @@ def _declared(header):
     return sorted(set(re.findall(r"\b(rth?_[a-z0-9_]+)\s*\(", text)))
 
 
+REF_BINDING = os.path.join(REPO, "oracle", "_ref", "ref_binding")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BINDING), reason="oracle/_ref/ref_binding is built only where the reference sources exist (make -C oracle ref)")
+@pytest.mark.parametrize("name", ["config1", "materials", "mesh1k_gi", "spheres_txt_dof", "readme_small"])
+def test_reference_side_binding_reproduces_the_reference(name, scene_path):
+    """oracle/ref_binding.cpp is the binding of include/rt_amd.h a maintainer of the reference would add, compiled against
+    the unmodified reference: it fills RtSceneDesc from the reference's own Scene members and calls the ABI. Through the CPU
+    restatement it must give the reference's own primary hits (Scene::findClosestObject) and, replaying the reference's
+    random stream, the frame of Scene::render(1), bit for bit."""
+    path = scene_path(name)
+    r = subprocess.run([REF_BINDING, os.path.basename(path), os.path.join(REPO, "oracle", "librt_oracle.so"), "rto_", "render"],
+                       cwd=os.path.dirname(path), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "BINDING OK" in r.stdout, r.stdout[-600:] + r.stderr[-600:]
+    assert ", 0 mismatches" in r.stdout and ", 0 differ" in r.stdout
+
+
 def test_libraries_export_every_declared_symbol():
     """Both shipped libraries load without a GPU and export exactly what include/*.h declares."""
     host = C.CDLL(os.path.join(REPO, "raytracer_amd", "librt_host.so"))
