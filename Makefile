@@ -13,7 +13,7 @@ HIPFLAGS  := -std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-s
 
 HOST_SRCS := $(HOSTDIR)/rth_scene.cpp $(HOSTDIR)/rth_bvh.cpp $(HOSTDIR)/rth_parse.cpp $(HOSTDIR)/rth_png.cpp $(HOSTDIR)/rth_capi.cpp
 HOST_HDRS := $(HOSTDIR)/rth_scene.h $(HOSTDIR)/rth_math.h $(HOSTDIR)/rth_threads.h $(ROOT)include/rt_amd.h $(ROOT)include/rt_host.h
-HIP_SRCS  := $(CSRC)/rt_device.hip
+HIP_SRCS  := $(CSRC)/rt_device.hip $(CSRC)/rt_bvh_build.hip
 HIP_HDRS  := $(wildcard $(CSRC)/*.h) $(ROOT)include/rt_amd.h
 
 .PHONY: all host hip cli oracle ref clean

@@ -118,6 +118,14 @@ typedef struct RtSceneDesc {
   const RtTexture *textures;
   RtCamera camera;
   RtOptions options;
+  /* Object bounding boxes, [numPrims*3] each: Object::aabbMin / aabbMax (src/scene/Object.h:48-49). Optional (may be
+   * NULL) when `nodes` is given. With nodes == NULL and numPrims > 0 they are required: the library then builds a BVH of
+   * its own on the device (a linear BVH: Morton order + radix tree, leaves of up to 4 objects) instead of taking the
+   * host-built tree of BVH::BVH (src/acceleration/BVH.cpp:72-281), and `prims` may be in any order. That tree is not the
+   * reference's: closest hits keep their t, but which of several objects hit at exactly the same t is reported, and the
+   * rare hits the reference's visit-order-dependent culling decides, may differ. */
+  const float *primAabbMin;
+  const float *primAabbMax;
 } RtSceneDesc;
 
 /* ---- rendering ---------------------------------------------------------------------- */
@@ -238,6 +246,11 @@ int rt_resolve_rgba8(RtScene *scene, uint8_t *rgba8Out);
 /* Device time (HIP events on the scene's stream) of the traversal kernel of the last rt_trace_primary / rt_trace_closest /
  * rt_trace_any call on this scene, in milliseconds; copies not included. */
 float rt_last_trace_kernel_ms(RtScene *scene);
+
+/* Device time (ms) of the BVH build rt_scene_create ran for this scene because RtSceneDesc.nodes was NULL; 0 when the
+ * scene came with a host-built tree. Replaces: the "BVH created" timing the reference prints after BVH::BVH
+ * (src/scene/raytracer.cpp:288). */
+float rt_scene_bvh_build_ms(RtScene *scene);
 
 const char *rt_last_error(void);
 const char *rt_version(void);

@@ -43,7 +43,10 @@ int rth_scene_set_options(RthScene *scene, const RtOptions *options);
 
 /* BVH::BVH (src/acceleration/BVH.cpp:161-182) + flattening into the RtSceneDesc arrays. */
 int rth_scene_build(RthScene *scene);
-/* Valid after rth_scene_build, until the scene is freed or rebuilt. */
+/* The RtSceneDesc arrays WITHOUT a tree (nodes = NULL, objects in the order the scene holds them, object boxes filled in):
+ * what rt_scene_create takes to build its own BVH on the GPU instead of BVH::BVH on the host. */
+int rth_scene_flatten_without_bvh(RthScene *scene);
+/* Valid after rth_scene_build / rth_scene_flatten_without_bvh, until the scene is freed or rebuilt. */
 const RtSceneDesc *rth_scene_desc(RthScene *scene);
 const char *rth_scene_filename(RthScene *scene);
 /* Lines the reference prints to stdout while loading/building ("Scanned ...", "BVH created with ..."). */

@@ -69,6 +69,7 @@ class RtSceneDesc(C.Structure):
         ("numLights", C.c_int32), ("lights", C.POINTER(RtLight)),
         ("numTextures", C.c_int32), ("textures", C.POINTER(RtTexture)),
         ("camera", RtCamera), ("options", RtOptions),
+        ("primAabbMin", C.POINTER(C.c_float)), ("primAabbMax", C.POINTER(C.c_float)),
     ]
 
 
@@ -130,6 +131,7 @@ def load_host_library():
     L.rth_scene_set_camera.argtypes = [vp, _f3, _f3, _f3]
     L.rth_scene_set_options.argtypes = [vp, C.POINTER(RtOptions)]
     L.rth_scene_build.argtypes = [vp]
+    L.rth_scene_flatten_without_bvh.argtypes = [vp]
     L.rth_scene_desc.restype = C.POINTER(RtSceneDesc); L.rth_scene_desc.argtypes = [vp]
     L.rth_scene_filename.restype = cp; L.rth_scene_filename.argtypes = [vp]
     L.rth_scene_log_count.restype = i32; L.rth_scene_log_count.argtypes = [vp]
@@ -246,6 +248,11 @@ class HostScene:
         self._check(self._L.rth_scene_build(self._h), "rth_scene_build")
         return self
 
+    def flatten_without_bvh(self):
+        """The scene description without a host-built tree (the device library then builds its own BVH)."""
+        self._check(self._L.rth_scene_flatten_without_bvh(self._h), "rth_scene_flatten_without_bvh")
+        return self
+
     @property
     def desc(self):
         d = self._L.rth_scene_desc(self._h)
@@ -332,6 +339,7 @@ def bind_render_abi(L, prefix):
         fn("trace_primary_static_max_pixels").restype = i64
     if hasattr(L, prefix + "last_trace_kernel_ms"):  # HIP library only
         fn("last_trace_kernel_ms").restype = C.c_float; fn("last_trace_kernel_ms").argtypes = [vp]
+        fn("scene_bvh_build_ms").restype = C.c_float; fn("scene_bvh_build_ms").argtypes = [vp]
     fn("framebuffer_read").argtypes = [vp, f32p]
     fn("device_count").restype = C.c_int
     fn("last_error").restype = C.c_char_p
@@ -435,6 +443,9 @@ class RenderScene:
         arr = (C.c_void_p * len(others))(*[o._h for o in others])
         self._check(self._f("framebuffer_gather")(self._h, arr, len(others)), "framebuffer_gather")
 
+    def bvh_build_ms(self):
+        return float(self._f("scene_bvh_build_ms")(self._h))
+
     def last_trace_kernel_ms(self):
         return float(self._f("last_trace_kernel_ms")(self._h))
 
@@ -464,5 +475,13 @@ def load_device_library():
     return _device
 
 
-def device_scene(desc, device=0):
+def device_scene(desc, device=0, build_on_device=False):
+    """Uploads the scene. build_on_device: hand it over WITHOUT the host-built tree (nodes = NULL); the library then builds
+    its own BVH on the GPU from the object boxes (RtSceneDesc.primAabbMin / primAabbMax)."""
+    if build_on_device:
+        d = RtSceneDesc()
+        C.pointer(d)[0] = desc.contents
+        d.nodes = None
+        d.numNodes = 0
+        desc = C.pointer(d)
     return RenderScene(load_device_library(), "rt_", desc, device)

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "rt_amd.h"
+#include "rt_bvh_build.h"
 #include "rt_dev_shade.h"
 #include "rt_dev_traverse.h"
 
@@ -508,6 +509,16 @@ __global__ __launch_bounds__(kBlock) void k_srgb8(const float4 *fb, uchar4 *out,
   out[i] = o;
 }
 
+// dst[i] = src[order[i]] for records of `dwords` 32-bit words: puts per-object arrays into the object order of a
+// device-built BVH
+__global__ __launch_bounds__(kBlock) void k_gather_records(const uint32_t *src, uint32_t *dst, const uint32_t *order, int64_t n, int32_t dwords) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n * dwords) return;
+  int64_t rec = i / dwords;
+  int32_t w = (int32_t)(i - rec * dwords);
+  dst[i] = src[(int64_t)order[rec] * dwords + w];
+}
+
 // ---------------------------------------------------------------------------------------------------- trace-only kernels
 RT_DEV int32_t reportedId(const DevScene &S, int32_t prim) {
   return prim < 0 ? -1 : (prim < S.numPrims ? __float_as_int(S.primShade[4 * (int64_t)prim + 3].w) : prim);
@@ -668,6 +679,7 @@ struct RtScene {
   size_t workBytes = 0;
   hipEvent_t workEvA = nullptr, workEvB = nullptr;
   float lastKernelMs = 0.0f;
+  float bvhBuildMs = 0.0f;  // device BVH build of rt_scene_create (0: the scene came with a host-built tree)
   std::vector<EventPair> events;
   size_t eventsUsed = 0;
   std::vector<PeerSlot> peers;
@@ -754,7 +766,11 @@ int validateDesc(const RtSceneDesc *d) {
   if (!d) return failMsg(RT_ERR_INVALID, "null scene description");
   if (d->numPrims < 0 || d->numNodes < 0 || d->numPlanes < 0 || d->numLights < 0 || d->numMaterials < 0 || d->numTextures < 0)
     return failMsg(RT_ERR_INVALID, "negative count in scene description");
-  if (d->numPrims > 0 && (!d->nodes || d->numNodes <= 0 || !d->primKind || !d->primHit || !d->primNormals || !d->primColor ||
+  if (d->numPrims > 0 && !d->nodes && (d->numNodes != 0 || !d->primAabbMin || !d->primAabbMax))
+    return failMsg(RT_ERR_INVALID, "a scene without BVH nodes needs primAabbMin / primAabbMax (and numNodes == 0) for the device build");
+  if (d->numPrims > 0 && !d->nodes && d->numPrims > (1 << 24))
+    return failMsg(RT_ERR_INVALID, "the device BVH build takes at most 2^24 objects: build the tree on the host");
+  if (d->numPrims > 0 && ((d->nodes && d->numNodes <= 0) || !d->primKind || !d->primHit || !d->primNormals || !d->primColor ||
                           !d->primMaterial || !d->primTexture || !d->primOrigIndex))
     return failMsg(RT_ERR_INVALID, "missing array in scene description");
   if (d->numPrims == 0 && d->numNodes != 0) return failMsg(RT_ERR_INVALID, "BVH nodes without objects");
@@ -836,6 +852,7 @@ int buildScene(RtScene *s, const RtSceneDesc *d) {
     }
     if (maxDepth > kMaxTreeDepth) return failMsg(RT_ERR_INVALID, "BVH deeper than the 64-entry traversal stack (depth " + std::to_string(maxDepth) + ")");
   }
+  const bool buildOnDevice = d->numPrims > 0 && !d->nodes;  // no host-built tree: a linear BVH is built below, on the GPU
   if (d->numNodes > 0) {
     dev.rootRef = childRef(0);
     std::memcpy(dev.rootMin, d->nodes[0].aabbMin, 12);
@@ -874,6 +891,45 @@ int buildScene(RtScene *s, const RtSceneDesc *d) {
   if ((rc = upload(s, nodes.data(), nodes.size(), &dev.nodes))) return rc;
   if ((rc = upload(s, primHit.data(), primHit.size(), &dev.primHit))) return rc;
   if ((rc = upload(s, bigLeaves.data(), bigLeaves.size(), &dev.bigLeaves))) return rc;
+  const uint32_t *order = nullptr;  // device build: object at tree position i = input object order[i]
+  // Re-orders an uploaded per-object array (records of `dwords` words) into tree order; the input-order copy is released.
+  auto reorder = [&](const void **arr, int32_t dwords) -> int {
+    if (!order || !*arr) return RT_OK;
+    void *dst = nullptr;
+    HIP_TRY(hipMalloc(&dst, n * (size_t)dwords * 4));
+    s->allocs.push_back(dst);
+    k_gather_records<<<(unsigned)(((int64_t)n * dwords + kBlock - 1) / kBlock), kBlock, 0, s->stream>>>(static_cast<const uint32_t *>(*arr), static_cast<uint32_t *>(dst), order,
+                                                                            (int64_t)n, dwords);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    void *old = const_cast<void *>(*arr);
+    s->allocs.erase(std::find(s->allocs.begin(), s->allocs.end(), old));
+    (void)hipFree(old);
+    *arr = dst;
+    return RT_OK;
+  };
+  if (buildOnDevice) {
+    const float *dMin = nullptr, *dMax = nullptr;
+    if ((rc = upload(s, d->primAabbMin, n * 3, &dMin))) return rc;
+    if ((rc = upload(s, d->primAabbMax, n * 3, &dMax))) return rc;
+    DeviceBvh bvh;
+    std::string err;
+    if (!buildLbvh(s->stream, dMin, dMax, d->numPrims, &bvh, err)) return failMsg(RT_ERR_DEVICE, err);
+    s->allocs.push_back(bvh.records);
+    s->allocs.push_back(bvh.order);
+    for (const float *p : {dMin, dMax}) {
+      s->allocs.erase(std::find(s->allocs.begin(), s->allocs.end(), static_cast<void *>(const_cast<float *>(p))));
+      (void)hipFree(const_cast<float *>(p));
+    }
+    dev.nodes = bvh.records;
+    dev.rootRef = bvh.rootRef;
+    std::memcpy(dev.rootMin, bvh.rootMin, 12);
+    std::memcpy(dev.rootMax, bvh.rootMax, 12);
+    if (!bvh.boxesFinite) dev.boxesFinite = 0;
+    s->bvhBuildMs = bvh.buildMs;
+    order = bvh.order;
+    if ((rc = reorder(reinterpret_cast<const void **>(&dev.primHit), 12))) return rc;
+  }
   {
     std::vector<float4> shade(n * 4);
     for (size_t i = 0; i < n; ++i) {
@@ -886,8 +942,16 @@ int buildScene(RtScene *s, const RtSceneDesc *d) {
       std::memcpy(rec + 60, &d->primOrigIndex[i], 4);
     }
     if ((rc = upload(s, shade.data(), shade.size(), &dev.primShade))) return rc;  // hipMalloc: 256-byte aligned
+    if ((rc = reorder(reinterpret_cast<const void **>(&dev.primShade), 16))) return rc;
   }
-  if (d->primTexCoords) { if ((rc = upload(s, d->primTexCoords, n * 9, &dev.primTexCoords))) return rc; }
+  if (d->primTexCoords) {
+    if ((rc = upload(s, d->primTexCoords, n * 9, &dev.primTexCoords))) return rc;
+    if ((rc = reorder(reinterpret_cast<const void **>(&dev.primTexCoords), 9))) return rc;
+  }
+  if (order) {
+    s->allocs.erase(std::find(s->allocs.begin(), s->allocs.end(), static_cast<void *>(const_cast<uint32_t *>(order))));
+    (void)hipFree(const_cast<uint32_t *>(order));
+  }
   // ---- planes, materials, lights, textures
   std::vector<DevPlane> planes(d->numPlanes);
   for (int32_t i = 0; i < d->numPlanes; ++i) {
@@ -1528,5 +1592,6 @@ int rt_resolve_rgba8(RtScene *s, uint8_t *rgba8Out) {
 }
 
 float rt_last_trace_kernel_ms(RtScene *s) { return s ? s->lastKernelMs : 0.0f; }
+float rt_scene_bvh_build_ms(RtScene *s) { return s ? s->bvhBuildMs : 0.0f; }
 
 }  // extern "C"

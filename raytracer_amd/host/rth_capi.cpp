@@ -212,6 +212,16 @@ int rth_scene_build(RthScene *h) {
   });
 }
 
+int rth_scene_flatten_without_bvh(RthScene *h) {
+  return guarded<int>(RT_ERR_NOMEM, [&]() -> int {
+    if (!h) return fail("null scene");
+    std::string err;
+    if (!flatten(*h->scene, h->flat, err, /*requireBvh*/ false)) return fail(err);
+    h->built = true;
+    return RT_OK;
+  });
+}
+
 const RtSceneDesc *rth_scene_desc(RthScene *h) {
   if (!h || !h->built) { fail("scene not built"); return nullptr; }
   return &h->flat.desc;

@@ -96,11 +96,12 @@ Plane makePlane(const Vec3 &normal, float D, const Color &color, int material, c
 
 static void put3(std::vector<float> &v, size_t at, const Vec3 &a) { v[at] = a.x; v[at + 1] = a.y; v[at + 2] = a.z; }
 
-bool flatten(const Scene &scene, FlatScene &out, std::string &error) {
-  if (!scene.bvhBuilt) { error = "flatten: buildBVH() has not run"; return false; }
+bool flatten(const Scene &scene, FlatScene &out, std::string &error, bool requireBvh) {
+  if (requireBvh && !scene.bvhBuilt) { error = "flatten: buildBVH() has not run"; return false; }
   size_t n = scene.prims.size();
   out.primKind.resize(n); out.primMaterial.resize(n); out.primTexture.resize(n); out.primOrigIndex.resize(n);
   out.primHit.assign(n * 12, 0.0f); out.primNormals.assign(n * 9, 0.0f); out.primColor.resize(n * 4);
+  out.primAabbMin.resize(n * 3); out.primAabbMax.resize(n * 3);
   bool anyTexturedTriangle = false;
   for (const Prim &p : scene.prims) anyTexturedTriangle |= (p.kind == RT_PRIM_TRIANGLE && p.texture >= 0);
   if (anyTexturedTriangle) out.primTexCoords.assign(n * 9, 0.0f); else out.primTexCoords.clear();
@@ -108,6 +109,7 @@ bool flatten(const Scene &scene, FlatScene &out, std::string &error) {
     const Prim &p = scene.prims[i];
     out.primKind[i] = p.kind; out.primMaterial[i] = p.material; out.primTexture[i] = p.texture;
     out.primOrigIndex[i] = p.origIndex;
+    put3(out.primAabbMin, i * 3, p.aabbMin); put3(out.primAabbMax, i * 3, p.aabbMax);
     if (p.kind == RT_PRIM_TRIANGLE) {
       put3(out.primHit, i * 12 + 0, p.p1); put3(out.primHit, i * 12 + 3, p.normal);
       put3(out.primHit, i * 12 + 6, p.e1); put3(out.primHit, i * 12 + 9, p.e2);
@@ -158,13 +160,14 @@ bool flatten(const Scene &scene, FlatScene &out, std::string &error) {
     }
   }
   RtSceneDesc &d = out.desc;
-  d.nodes = reinterpret_cast<const RtBvhNode *>(scene.nodes.data());
-  d.numNodes = (int32_t)scene.nodes.size();
+  d.nodes = requireBvh ? reinterpret_cast<const RtBvhNode *>(scene.nodes.data()) : nullptr;
+  d.numNodes = requireBvh ? (int32_t)scene.nodes.size() : 0;
   d.numPrims = (int32_t)n;
   d.primKind = out.primKind.data(); d.primHit = out.primHit.data(); d.primNormals = out.primNormals.data();
   d.primTexCoords = out.primTexCoords.empty() ? nullptr : out.primTexCoords.data();
   d.primColor = out.primColor.data(); d.primMaterial = out.primMaterial.data();
   d.primTexture = out.primTexture.data(); d.primOrigIndex = out.primOrigIndex.data();
+  d.primAabbMin = out.primAabbMin.data(); d.primAabbMax = out.primAabbMax.data();
   d.numPlanes = (int32_t)out.planes.size(); d.planes = out.planes.data();
   d.numMaterials = (int32_t)out.materials.size(); d.materials = out.materials.data();
   d.numLights = (int32_t)out.lights.size(); d.lights = out.lights.data();

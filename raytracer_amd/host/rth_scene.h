@@ -133,12 +133,14 @@ void toSRGB8(const float *rgba, size_t numPixels, uint8_t *rgba8);              
 struct FlatScene {
   RtSceneDesc desc{};
   std::vector<int32_t> primKind, primMaterial, primTexture, primOrigIndex;
+  std::vector<float> primAabbMin, primAabbMax;  // 3 per object: Object::aabbMin / aabbMax
   std::vector<float> primHit, primNormals, primTexCoords, primColor;
   std::vector<RtPlane> planes;
   std::vector<RtLight> lights;
   std::vector<RtTexture> textures;
   std::vector<RtMaterial> materials;
 };
-bool flatten(const Scene &scene, FlatScene &out, std::string &error);
+// requireBvh = false: objects in whatever order the scene holds them, no nodes (the device library builds its own tree)
+bool flatten(const Scene &scene, FlatScene &out, std::string &error, bool requireBvh = true);
 
 }  // namespace rth

@@ -65,3 +65,9 @@ def test_cli_renders_the_scene_file(scene_path, tmp_path):
     ids, t = dev.trace_primary()
     assert np.array_equal(raw[:, 0].view(np.int32), ids.reshape(-1)) and np.array_equal(raw[:, 1], t.reshape(-1).view(np.uint32))
     dev.close()
+    # --device-bvh: no host tree, the GPU builds its own; same t for every primary ray
+    dump2 = str(tmp_path / "hits_device_bvh.bin")
+    r = run("--device-bvh", "--dump-hits", dump2, src, cwd=os.path.dirname(src))
+    assert r.returncode == 0 and "BVH built on the GPU" in r.stdout, r.stdout + r.stderr
+    raw2 = np.fromfile(dump2, dtype=np.uint32).reshape(-1, 2)
+    assert np.array_equal(raw2[:, 1], raw[:, 1])
