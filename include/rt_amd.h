@@ -146,6 +146,20 @@ typedef struct RtRenderParams {
                            * in half of the free device memory, at most 64 GiB of path state (184 B per path with 2 lights) */
   int32_t collectCounters;/* non-zero: count traversal work (inner expansions, primitive tests); slower */
   int32_t skipExposure;   /* non-zero: leave out Scene::expose (src/scene/raytracer.cpp:303-312) */
+  /* ---- extensions of the sample loop `for (i = 0; i < numRays; ++i)` (src/scene/raytracer.cpp:41-52); all zero = the
+   * reference's loop. Sample i of a pixel is the same camera sample in every mode (the random stream is keyed on it). */
+  /* Progressive rendering: this call traces samples [firstSample, firstSample + sampleCount) of every pixel
+   * (sampleCount 0 = up to options.numRays) and, with keepAccumulator, adds them to the per-pixel sums the previous
+   * call(s) on this scene left (same image size and tile partition required). The frame written is the estimate from
+   * all samples accumulated so far (alpha = valid samples / samples taken); once all numRays samples are in, it is
+   * bit for bit the frame of a single call. */
+  int32_t firstSample, sampleCount, keepAccumulator;
+  /* Adaptive sampling (adaptiveThreshold > 0): every adaptiveBatch samples (0 = 16), and not before adaptiveMinSamples
+   * (0 = one batch), a pixel stops taking samples when the standard error of the mean luminance of its valid samples,
+   * sqrt(var / n), is at most adaptiveThreshold * (mean + 0.05), or when it has no valid sample at all. Fewer camera
+   * samples than the reference takes; the estimator of a pixel is the reference's over the samples it did take. */
+  float adaptiveThreshold;
+  int32_t adaptiveBatch, adaptiveMinSamples;
 } RtRenderParams;
 
 typedef struct RtStats {

@@ -176,6 +176,13 @@ struct Hit {
 
 }  // namespace
 
+// Per-pixel state of the sample loop that outlives a call (progressive rendering, RtRenderParams::keepAccumulator).
+struct PixelAcc {
+  RGBA sum = RGBA(0, 0, 0, 0);
+  int hits = 0, taken = 0;
+  float lumSum = 0, lumSqSum = 0;
+};
+
 struct RtoScene {
   std::vector<RtBvhNode> nodes;
   int numPrims = 0;
@@ -188,6 +195,7 @@ struct RtoScene {
   RtCamera camera;
   RtOptions options;
   std::vector<float> framebuffer;
+  std::vector<PixelAcc> acc;  // per-pixel sums of the sample loop, kept for RtRenderParams::keepAccumulator
   int threads = 1;
 };
 
@@ -774,30 +782,47 @@ CameraMode cameraMode(const RtoScene &s) {
   return cm;
 }
 
-// The per-pixel body of threadTaskDefault/Fisheye/DOF (:36-59 and twins)
-RGBA renderPixel(const RtoScene &s, const CameraMode &cm, int x, int y, Sampler *shared, uint32_t seed) {
+// The per-pixel body of threadTaskDefault/Fisheye/DOF (:36-59 and twins): samples [first, end) of the loop
+// `for i < numRays`, added to `acc`; with threshold > 0 the pixel stops at a batch boundary once its luminance estimate
+// has converged (the rule of RtRenderParams::adaptiveThreshold). All-zero extensions = the reference's loop.
+RGBA renderPixel(const RtoScene &s, const CameraMode &cm, int x, int y, Sampler *shared, uint32_t seed, PixelAcc &acc, int first, int end,
+                 float threshold = 0.0f, int batch = 16, int minSamples = 16) {
   const RtOptions &o = s.options;
-  float invNumRays = 1.0 / o.numRays;
   int allowAA = std::min(1, o.numRays - 1);
-  RGBA avg(0, 0, 0, 0);
-  int hits = 0;
   CounterSampler cs;
-  for (int i = 0; i < o.numRays; ++i) {
+  for (int i = first; i < end; ++i) {
     Sampler *sampler = shared;
     if (!sampler) {
       cs.seed(seed, (uint32_t)(y * o.width + x), (uint32_t)i);
       sampler = &cs;
     }
     RGBA color;
-    if (!cameraSample(s, cm, x, y, allowAA, *sampler, &color)) continue;
-    if (hasNaN(color) == false && color.a != 0) {
-      addAssign(avg, color);
-      ++hits;
+    bool traced = cameraSample(s, cm, x, y, allowAA, *sampler, &color);
+    ++acc.taken;
+    if (traced && hasNaN(color) == false && color.a != 0) {
+      addAssign(acc.sum, color);
+      ++acc.hits;
+      if (threshold > 0) {
+        float yv = (0.2126f * color.r + 0.7152f * color.g) + 0.0722f * color.b;
+        acc.lumSum += yv;
+        acc.lumSqSum += yv * yv;
+      }
+    }
+    if (threshold > 0 && (i + 1 - first) % batch == 0 && acc.taken < o.numRays && acc.taken >= minSamples) {
+      if (acc.hits == 0) break;
+      if (acc.hits >= 2) {
+        float mean = acc.lumSum / (float)acc.hits;
+        float var = std::max(0.0f, acc.lumSqSum - acc.lumSum * mean) / (float)(acc.hits - 1);
+        float se = std::sqrt(var / (float)acc.hits);
+        if (se <= threshold * (mean + 0.05f)) break;
+      }
     }
   }
-  if (hits != 0) {
-    mulAssign(avg, 1.0f / hits);
-    avg.a = hits * invNumRays;
+  RGBA avg = acc.sum;
+  float invNumRays = 1.0 / std::max(1, acc.taken);  // = 1.0 / numRays once the whole loop has run (:39)
+  if (acc.hits != 0) {
+    mulAssign(avg, 1.0f / acc.hits);
+    avg.a = acc.hits * invNumRays;
   }
   return clipColor(avg);
 }
@@ -935,13 +960,22 @@ int rto_render(RtoScene *s, const RtRenderParams *params, float *rgbaOut, RtStat
   s->framebuffer.assign((size_t)W * H * 4, 0.0f);
   CameraMode cm = cameraMode(*s);
   Counters total;
+  const int sFirst = params->firstSample;
+  if (sFirst < 0 || sFirst >= o.numRays || params->sampleCount < 0) return fail("firstSample / sampleCount outside 0 .. numRays");
+  const int sEnd = params->sampleCount > 0 ? std::min(o.numRays, sFirst + params->sampleCount) : o.numRays;
+  const bool adaptive = params->adaptiveThreshold > 0.0f;
+  const int batch = params->adaptiveBatch > 0 ? params->adaptiveBatch : 16;
+  const int minSamples = params->adaptiveMinSamples > 0 ? params->adaptiveMinSamples : batch;
+  if (adaptive && (sFirst != 0 || params->keepAccumulator)) return fail("adaptive sampling starts at sample 0 with an empty accumulator");
+  if (params->keepAccumulator && s->acc.size() != (size_t)W * H) return fail("keepAccumulator needs a previous render of the same image size");
+  if (!params->keepAccumulator) s->acc.assign((size_t)W * H, PixelAcc());
   if (params->rngMode == RT_RNG_REF_MT19937) {
     // one worker, one generator, row-major pixel order: the reference at -t1 (raytracer.cpp:33, 269-273)
     MtSampler sampler;
     tl_counters = &total;
     for (int y = 0; y < H; ++y)
       for (int x = 0; x < W; ++x) {
-        RGBA px = renderPixel(*s, cm, x, y, &sampler, 0);
+        RGBA px = renderPixel(*s, cm, x, y, &sampler, 0, s->acc[(size_t)y * W + x], sFirst, sEnd);
         std::memcpy(&s->framebuffer[((size_t)y * W + x) * 4], &px, 16);
       }
     tl_counters = nullptr;
@@ -949,7 +983,8 @@ int rto_render(RtoScene *s, const RtRenderParams *params, float *rgbaOut, RtStat
     parallelRows(s->threads, H, &total, [&](int y) {
       for (int x = 0; x < W; ++x) {
         if (!inPartition(*params, W, x, y)) continue;
-        RGBA px = renderPixel(*s, cm, x, y, nullptr, params->seed);
+        RGBA px = renderPixel(*s, cm, x, y, nullptr, params->seed, s->acc[(size_t)y * W + x], sFirst, sEnd,
+                              adaptive ? params->adaptiveThreshold : 0.0f, batch, minSamples);
         std::memcpy(&s->framebuffer[((size_t)y * W + x) * 4], &px, 16);
       }
     });

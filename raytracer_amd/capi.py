@@ -76,7 +76,9 @@ class RtSceneDesc(C.Structure):
 class RtRenderParams(C.Structure):
     _fields_ = [("rngMode", C.c_int32), ("seed", C.c_uint32), ("partIndex", C.c_int32), ("partCount", C.c_int32),
                 ("tileW", C.c_int32), ("tileH", C.c_int32), ("samplesPerPass", C.c_int32),
-                ("collectCounters", C.c_int32), ("skipExposure", C.c_int32)]
+                ("collectCounters", C.c_int32), ("skipExposure", C.c_int32),
+                ("firstSample", C.c_int32), ("sampleCount", C.c_int32), ("keepAccumulator", C.c_int32),
+                ("adaptiveThreshold", C.c_float), ("adaptiveBatch", C.c_int32), ("adaptiveMinSamples", C.c_int32)]
 
 
 class RtStats(C.Structure):
@@ -414,11 +416,14 @@ class RenderScene:
         return occ
 
     def render(self, rng_mode=RT_RNG_COUNTER, seed=56, part_index=0, part_count=1, tile=(32, 32), samples_per_pass=0,
-               collect_counters=False, skip_exposure=False, download=True, out_ptr=None):
+               collect_counters=False, skip_exposure=False, download=True, out_ptr=None, first_sample=0, sample_count=0,
+               keep_accumulator=False, adaptive_threshold=0.0, adaptive_batch=0, adaptive_min_samples=0):
         """out_ptr: optional raw pointer (host or device memory of width*height*4 floats) that receives the frame
-        instead of a fresh numpy array."""
+        instead of a fresh numpy array. first_sample / sample_count / keep_accumulator: progressive rendering;
+        adaptive_*: adaptive sampling (see RtRenderParams in include/rt_amd.h)."""
         p = RtRenderParams(rng_mode, seed, part_index, part_count, tile[0], tile[1], samples_per_pass,
-                           int(collect_counters), int(skip_exposure))
+                           int(collect_counters), int(skip_exposure), first_sample, sample_count, int(keep_accumulator),
+                           adaptive_threshold, adaptive_batch, adaptive_min_samples)
         st = RtStats()
         out = None
         if out_ptr is not None:

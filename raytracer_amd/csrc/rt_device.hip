@@ -80,6 +80,7 @@ struct PathBuf {
   Counts *counts;
   int32_t P, npix;
   int32_t spp;  // samples per pixel in this pass; path slot = pixel position * spp + sample, so a pixel's samples are neighbours
+  const int32_t *active;  // adaptive sampling: positions (in the pixel list) of the pixels this pass samples; nullptr = all, in order
 };
 static_assert(offsetof(Counts, nNext) == offsetof(Counts, nHit) + 4 && offsetof(Counts, nHit) % 8 == 0, "nHit/nNext form one 64-bit word");
 
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DevScene S, PathBuf B, const 
   bool alive = false;
   if (valid) {
     int32_t p = (int32_t)(i / sppThis), s = (int32_t)(i % sppThis);
-    int32_t pixel = pixList[p];
+    int32_t pixel = pixList[B.active ? B.active[p] : p];
     int32_t x = pixel % S.width, y = pixel / S.width;
     Rng rng = rngInit(seed, (uint32_t)pixel, (uint32_t)(sampleBase + s), 0u);
     int allowAA = min(1, S.numRays - 1);
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
     float t = B.hitT[slot];
     // the path's random stream is a function of its pixel and sample index; only the draw count is stored
     const uint32_t pixPos = slot / (uint32_t)B.spp, sampleInPass = slot - pixPos * (uint32_t)B.spp;
-    Rng rng = rngInit(seed, (uint32_t)pixList[pixPos], (uint32_t)sampleBase + sampleInPass, B.rng[slot]);
+    Rng rng = rngInit(seed, (uint32_t)pixList[B.active ? B.active[pixPos] : (int32_t)pixPos], (uint32_t)sampleBase + sampleInPass, B.rng[slot]);
     float4 beta4 = B.beta[slot];
     V3 o = v3(o4.x, o4.y, o4.z), d = v3(d4.x, d4.y, d4.z);
     const bool onObject = prim >= 0 && prim < S.numPrims;
@@ -440,31 +441,73 @@ __global__ void k_begin_pass(PathBuf B, uint32_t nActive) {
 }
 __global__ void k_count_samples(PathBuf B, unsigned long long n) { B.counts->samples += n; }  // rejected fisheye samples count too
 
-// Per pixel: fold this pass's samples, in sample order, into the running sum (raytracer.cpp:48-51).
-__global__ __launch_bounds__(kBlock) void k_accumulate(PathBuf B, float4 *pixSum, int32_t *pixHits, int32_t sppThis) {
+// Per-pixel state of the sample loop that outlives a pass (and, for progressive rendering, a call).
+struct PixelAcc {
+  float4 *sum;       // running colour sum of the valid samples (raytracer.cpp:48-51)
+  int32_t *hits;     // number of valid samples
+  int32_t *taken;    // number of samples taken (the loop counter `i` of raytracer.cpp:41)
+  float *lumSum, *lumSqSum;  // adaptive sampling: sum and sum of squares of the valid samples' luminance
+};
+
+// Per pixel of this pass: fold the pass's samples, in sample order, into the running sum (raytracer.cpp:48-51). With
+// adaptive sampling (threshold > 0) the pixel then decides whether it goes on (see RtRenderParams): pixels that do are
+// appended to `nextActive`.
+__global__ __launch_bounds__(kBlock) void k_accumulate(PathBuf B, PixelAcc A, int32_t nPix, int32_t sppThis, float threshold, int32_t minSamples,
+                                                       int32_t maxSamples, int32_t *nextActive, uint32_t *nextCount) {
   int32_t p = blockIdx.x * kBlock + threadIdx.x;
-  if (p >= B.npix) return;
-  RGBA avg = rgba(pixSum[p]);
-  int hits = pixHits[p];
-  for (int s = 0; s < sppThis; ++s) {
-    RGBA color = rgba(B.L[(int64_t)p * sppThis + s]);
-    if (hasNaN(color) == false && color.a != 0) {
-      addAssign(avg, color);
-      ++hits;
+  bool goesOn = false;
+  int32_t fp = 0;
+  if (p < nPix) {
+    fp = B.active ? B.active[p] : p;
+    RGBA avg = rgba(A.sum[fp]);
+    int hits = A.hits[fp];
+    float s1 = 0.0f, s2 = 0.0f;
+    if (threshold > 0) { s1 = A.lumSum[fp]; s2 = A.lumSqSum[fp]; }
+    for (int s = 0; s < sppThis; ++s) {
+      RGBA color = rgba(B.L[(int64_t)p * sppThis + s]);
+      if (hasNaN(color) == false && color.a != 0) {
+        addAssign(avg, color);
+        ++hits;
+        if (threshold > 0) {
+          float y = (0.2126f * color.r + 0.7152f * color.g) + 0.0722f * color.b;
+          s1 += y;
+          s2 += y * y;
+        }
+      }
+    }
+    const int32_t taken = A.taken[fp] + sppThis;
+    A.sum[fp] = f4(avg);
+    A.hits[fp] = hits;
+    A.taken[fp] = taken;
+    if (threshold > 0) {
+      A.lumSum[fp] = s1; A.lumSqSum[fp] = s2;
+      goesOn = taken < maxSamples;
+      if (goesOn && taken >= minSamples) {
+        if (hits == 0) {
+          goesOn = false;
+        } else if (hits >= 2) {
+          float mean = s1 / (float)hits;
+          float var = rmax(0.0f, s2 - s1 * mean) / (float)(hits - 1);
+          float se = sqrtf(var / (float)hits);
+          goesOn = !(se <= threshold * (mean + 0.05f));
+        }
+      }
     }
   }
-  pixSum[p] = f4(avg);
-  pixHits[p] = hits;
+  if (threshold > 0) {
+    uint32_t q = queueSlot(nextCount, goesOn);
+    if (goesOn) nextActive[q] = fp;
+  }
 }
 
 // raytracer.cpp:54-59 then Scene::expose (:303-312)
-__global__ __launch_bounds__(kBlock) void k_resolve(DevScene S, int32_t npix, const int32_t *pixList, const float4 *pixSum,
-                                                    const int32_t *pixHits, float4 *fb, float4 *packed, int32_t applyExposure) {
+__global__ __launch_bounds__(kBlock) void k_resolve(DevScene S, int32_t npix, const int32_t *pixList, PixelAcc A, float4 *fb, float4 *packed,
+                                                    int32_t applyExposure) {
   int32_t p = blockIdx.x * kBlock + threadIdx.x;
   if (p >= npix) return;
-  RGBA avg = rgba(pixSum[p]);
-  int hits = pixHits[p];
-  float invNumRays = (float)(1.0 / (double)S.numRays);
+  RGBA avg = rgba(A.sum[p]);
+  int hits = A.hits[p];
+  float invNumRays = (float)(1.0 / (double)max(1, A.taken[p]));  // = 1.0 / numRays once the whole loop has run (raytracer.cpp:39)
   if (hits != 0) {
     mulAssign(avg, 1.0f / hits);
     avg.a = hits * invNumRays;
@@ -665,14 +708,19 @@ struct RtScene {
   size_t arenaBytes = 0;
   int64_t arenaP = 0;
   int32_t *pixList = nullptr;
-  float4 *pixSum = nullptr;
-  int32_t *pixHits = nullptr;
+  // per-pixel state of the sample loop (kept between calls for progressive rendering) and the active-pixel lists of
+  // adaptive sampling: ONE allocation, carved in ensureRenderBuffers
+  void *pixState = nullptr;
+  PixelAcc acc{};
+  int32_t *activeA = nullptr, *activeB = nullptr;
+  uint32_t *activeCount = nullptr;  // two counters, 128 bytes apart
   float4 *fb = nullptr;
   float4 *packed = nullptr;  // this partition's resolved pixels in pixel-list order: what a gather moves to another GPU
   int64_t fbPixels = 0, pixCap = 0;
   // the pixel list on the device belongs to this partition (a repeated frame does not rebuild and re-upload it)
   int pixKey[6] = {-1, -1, -1, -1, -1, -1};
   int64_t pixCount = 0;
+  bool accValid = false;  // the per-pixel sums hold the samples of a finished rt_render on this partition (what keepAccumulator adds to)
   Counts *counts = nullptr;
   // staging of the trace-only and conversion entry points: grow-only, so a repeated call of the same size allocates nothing
   void *work = nullptr;
@@ -1035,15 +1083,22 @@ int ensureRenderBuffers(RtScene *s, int64_t P, int64_t npix, int64_t fbPixels) {
   }
   if (s->pixCap < npix) {
     if (s->pixList) (void)hipFree(s->pixList);
-    if (s->pixSum) (void)hipFree(s->pixSum);
-    if (s->pixHits) (void)hipFree(s->pixHits);
+    if (s->pixState) (void)hipFree(s->pixState);
     if (s->packed) (void)hipFree(s->packed);
-    s->pixList = nullptr; s->pixSum = nullptr; s->pixHits = nullptr; s->packed = nullptr;
+    s->pixList = nullptr; s->pixState = nullptr; s->packed = nullptr;
     s->pixKey[0] = -1;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->pixList), npix * sizeof(int32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->pixSum), npix * sizeof(float4)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->pixHits), npix * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&s->pixState, (size_t)npix * (sizeof(float4) + 6 * 4) + 256));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->packed), npix * sizeof(float4)));
+    char *ps = static_cast<char *>(s->pixState);
+    s->acc.sum = reinterpret_cast<float4 *>(ps); ps += (size_t)npix * sizeof(float4);
+    s->acc.hits = reinterpret_cast<int32_t *>(ps); ps += (size_t)npix * 4;
+    s->acc.taken = reinterpret_cast<int32_t *>(ps); ps += (size_t)npix * 4;
+    s->acc.lumSum = reinterpret_cast<float *>(ps); ps += (size_t)npix * 4;
+    s->acc.lumSqSum = reinterpret_cast<float *>(ps); ps += (size_t)npix * 4;
+    s->activeA = reinterpret_cast<int32_t *>(ps); ps += (size_t)npix * 4;
+    s->activeB = reinterpret_cast<int32_t *>(ps); ps += (size_t)npix * 4;
+    s->activeCount = reinterpret_cast<uint32_t *>(ps);
     s->pixCap = npix;
   }
   if (s->arenaP < P) {
@@ -1188,8 +1243,7 @@ void rt_scene_destroy(RtScene *s) {
   for (void *p : s->allocs) (void)hipFree(p);
   if (s->arena) (void)hipFree(s->arena);
   if (s->pixList) (void)hipFree(s->pixList);
-  if (s->pixSum) (void)hipFree(s->pixSum);
-  if (s->pixHits) (void)hipFree(s->pixHits);
+  if (s->pixState) (void)hipFree(s->pixState);
   if (s->fb) (void)hipFree(s->fb);
   if (s->packed) (void)hipFree(s->packed);
   if (s->work) (void)hipFree(s->work);
@@ -1355,9 +1409,19 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
   const DevScene &S = s->dev;
   int W = S.width, H = S.height;
   if (S.numRays <= 0) return failMsg(RT_ERR_INVALID, "numRays must be positive");
+  // the window of the sample loop this call runs
+  const int sFirst = params->firstSample;
+  if (sFirst < 0 || sFirst >= S.numRays || params->sampleCount < 0) return failMsg(RT_ERR_INVALID, "firstSample / sampleCount outside 0 .. numRays");
+  const int sEnd = params->sampleCount > 0 ? std::min(S.numRays, sFirst + params->sampleCount) : S.numRays;
+  const bool adaptive = params->adaptiveThreshold > 0.0f;
+  const int adaptiveBatch = params->adaptiveBatch > 0 ? params->adaptiveBatch : 16;
+  const int adaptiveMin = params->adaptiveMinSamples > 0 ? params->adaptiveMinSamples : adaptiveBatch;
+  if (adaptive && (sFirst != 0 || params->keepAccumulator)) return failMsg(RT_ERR_INVALID, "adaptive sampling starts at sample 0 with an empty accumulator");
   const int key[6] = {W, H, params->partIndex, params->partCount, params->tileW, params->tileH};
   const bool samePartition = s->pixList && std::memcmp(key, s->pixKey, sizeof key) == 0;
   std::vector<int32_t> pix;
+  if (params->keepAccumulator && (!samePartition || !s->accValid))
+    return failMsg(RT_ERR_INVALID, "keepAccumulator needs a previous rt_render on this scene with the same image size and tile partition");
   if (!samePartition) pix = buildPixelList(*params, W, H);
   int64_t npix = samePartition ? s->pixCount : (int64_t)pix.size();
   int64_t fbPixels = (int64_t)W * H;
@@ -1373,8 +1437,9 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
     const size_t perPath = sizeof(float4) * (7 + std::max(1, s->numEnvLights) + std::max(1, s->dev.numLights)) + 4 * 6;
     sppPass = (int)std::min<size_t>((size_t)S.numRays, std::max<size_t>(1, budget / (perPath * (size_t)std::max<int64_t>(1, npix))));
   }
-  const bool sppPassChosenHere = params->samplesPerPass <= 0;
-  sppPass = std::min(sppPass, S.numRays);
+  bool sppPassChosenHere = params->samplesPerPass <= 0;
+  sppPass = std::min(sppPass, sEnd - sFirst);
+  if (adaptive) { sppPass = std::min(adaptiveBatch, S.numRays); sppPassChosenHere = false; }  // pixels decide at batch boundaries
   // path slots are 31-bit indices, and the visibility queue (one entry per hit and light) is indexed with 32 bits
   const int64_t maxPaths = std::min<int64_t>(((int64_t)1 << 31) - 1, (((int64_t)1 << 32) - ((int64_t)1 << 24)) / std::max(1, S.numLights));
   if (sppPassChosenHere) sppPass = (int)std::max<int64_t>(1, std::min<int64_t>(sppPass, maxPaths / std::max<int64_t>(1, npix)));
@@ -1405,8 +1470,7 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
       std::memcpy(s->pixKey, key, sizeof key);
       s->pixCount = npix;
     }
-    HIP_TRY(hipMemsetAsync(s->pixSum, 0, npix * sizeof(float4), st));
-    HIP_TRY(hipMemsetAsync(s->pixHits, 0, npix * sizeof(int32_t), st));
+    if (!params->keepAccumulator) HIP_TRY(hipMemsetAsync(s->acc.sum, 0, (size_t)s->pixCap * (sizeof(float4) + 4 * 4), st));  // sum, hits, taken, lumSum, lumSqSum: carved back to back for pixCap pixels
   } else {
     std::memcpy(s->pixKey, key, sizeof key);  // an empty partition: nothing to trace, nothing for a gather to move
     s->pixCount = 0;
@@ -1415,10 +1479,15 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
   size_t totalIdx = s->eventsUsed;
   if (timing) ++s->eventsUsed;  // the total pair stays open until the end
   uint32_t passes = 0, launchesExtend = 0, launchesShadow = 0;
-  for (int sBase = 0; npix > 0 && sBase < S.numRays; sBase += sppPass, ++passes) {
-    int sppThis = std::min(sppPass, S.numRays - sBase);
-    int64_t n = npix * sppThis;
+  int64_t nPixPass = npix;            // pixels that take samples in the next pass (adaptive sampling shrinks it)
+  int32_t *activeCur = nullptr, *activeNext = s->activeA;
+  s->accValid = false;
+  for (int sBase = sFirst; nPixPass > 0 && sBase < sEnd; sBase += sppPass, ++passes) {
+    int sppThis = std::min(sppPass, sEnd - sBase);
+    int64_t n = nPixPass * sppThis;
     B.spp = sppThis;
+    B.npix = (int32_t)nPixPass;
+    B.active = activeCur;
     unsigned grid = gridFor(n);
     k_begin_pass<<<1, 1, 0, st>>>(B, S.cameraMode == 1 ? 0u : (uint32_t)n);
     if ((rc = beginEvent(s, CAT_RAYGEN, timing))) return rc;
@@ -1450,13 +1519,26 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
       std::swap(qCur, qNext);
     }
     if ((rc = beginEvent(s, CAT_ACCUM, timing))) return rc;
-    k_accumulate<<<gridFor(npix), kBlock, 0, st>>>(B, s->pixSum, s->pixHits, sppThis);
+    uint32_t *nextCount = s->activeCount + (passes & 1u) * 32u;
+    if (adaptive) HIP_TRY(hipMemsetAsync(nextCount, 0, sizeof(uint32_t), st));
+    k_accumulate<<<gridFor(nPixPass), kBlock, 0, st>>>(B, s->acc, (int32_t)nPixPass, sppThis, adaptive ? params->adaptiveThreshold : 0.0f, adaptiveMin,
+                                                       S.numRays, activeNext, nextCount);
     if ((rc = endEvent(s, timing))) return rc;
+    if (adaptive) {
+      // the next pass is sized by the number of pixels that go on: one small read-back per batch
+      uint32_t left = 0;
+      HIP_TRY(hipMemcpyAsync(&left, nextCount, sizeof left, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      nPixPass = left;
+      activeCur = activeNext;
+      activeNext = activeCur == s->activeA ? s->activeB : s->activeA;
+    }
   }
+  s->accValid = true;
   if (npix > 0) {
     if ((rc = beginEvent(s, CAT_RESOLVE, timing))) return rc;
     int applyExposure = (S.exposure >= 0 && !params->skipExposure) ? 1 : 0;
-    k_resolve<<<gridFor(npix), kBlock, 0, st>>>(S, (int32_t)npix, s->pixList, s->pixSum, s->pixHits, s->fb, s->packed, applyExposure);
+    k_resolve<<<gridFor(npix), kBlock, 0, st>>>(S, (int32_t)npix, s->pixList, s->acc, s->fb, s->packed, applyExposure);
     if ((rc = endEvent(s, timing))) return rc;
   }
   if (timing) HIP_TRY(hipEventRecord(s->events[totalIdx].b, st));

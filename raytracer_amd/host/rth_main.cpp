@@ -13,6 +13,8 @@
 //   --seed N        seed of the counter-based random stream (default 56, the reference's unused `seed` default)
 //   --dump-hits F   write primary-ray hit ids and t (int32, float32 per pixel, row-major) to F and exit
 //   --stats         print ray counts, Mrays/s and per-kernel milliseconds
+//   --adaptive T    adaptive sampling: a pixel stops taking samples once the standard error of its mean luminance is at
+//                   most T * (mean + 0.05), checked every --adaptive-batch samples (default 16)
 //   --device-bvh    skip the host BVH build; the GPU builds a linear BVH of its own (milliseconds instead of seconds for
 //                   millions of objects; not the reference's tree: objects hit at exactly equal t may swap)
 // `-t` keeps meaning host threads: it sets how many the parsers and the BVH build use (default: all, at most 16).
@@ -56,6 +58,8 @@ int main(int argc, char **argv) {
   int gpus = 1, tileW = 32, tileH = 32, sppPass = 0;
   unsigned seed = 56;
   bool stats = false, shareGpus = false, deviceBvh = false;
+  float adaptive = 0.0f;
+  int adaptiveBatch = 0;
   std::string dumpHits, path;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -73,6 +77,8 @@ int main(int argc, char **argv) {
     else if (a == "--stats") stats = true;
     else if (a == "--share-gpus") shareGpus = true;
     else if (a == "--device-bvh") deviceBvh = true;
+    else if (a == "--adaptive") adaptive = (float)std::atof(next("--adaptive"));
+    else if (a == "--adaptive-batch") adaptiveBatch = std::atoi(next("--adaptive-batch"));
     else if (!a.empty() && a[0] == '-') return usage(argv[0], -1);
     else path = a;
   }
@@ -144,6 +150,7 @@ int main(int argc, char **argv) {
   if (gpus == 1) {
     RtRenderParams p{};
     p.rngMode = RT_RNG_COUNTER; p.seed = seed; p.partCount = 1; p.tileW = tileW; p.tileH = tileH; p.samplesPerPass = sppPass;
+    p.adaptiveThreshold = adaptive; p.adaptiveBatch = adaptiveBatch;
     rc[0] = rt_render(scenes[0], &p, frame.data(), &st[0]);
     if (rc[0] != RT_OK) errs[0] = rt_last_error();
   } else {
@@ -156,6 +163,7 @@ int main(int argc, char **argv) {
         RtRenderParams p{};
         p.rngMode = RT_RNG_COUNTER; p.seed = seed; p.partIndex = g; p.partCount = gpus; p.tileW = tileW; p.tileH = tileH;
         p.samplesPerPass = sppPass;
+        p.adaptiveThreshold = adaptive; p.adaptiveBatch = adaptiveBatch;
         rc[g] = rt_render(scenes[g], &p, nullptr, &st[g]);
         if (rc[g] != RT_OK) errs[g] = rt_last_error();
       });

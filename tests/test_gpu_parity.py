@@ -280,6 +280,33 @@ def test_device_to_device_gather_of_tile_partitions(scenes):
             p.close()
 
 
+@pytest.mark.parametrize("name", ["mesh1k_gi", "readme_small", "spheres_txt_fisheye"])
+def test_progressive_and_adaptive_sampling(name, scenes):
+    """The extended sample loop on the GPU. Progressive: sample windows added up (keepAccumulator) give the frame of a
+    single call bit for bit, whatever the pass size. Adaptive: the same stopping rule as the CPU restatement at matched
+    streams — nearly the same number of camera samples (a last-bit difference in a luminance can move a pixel's stop by
+    one batch) and a frame within the PSNR bar of the restatement's adaptive frame ; adaptive sampling that may not stop before the last sample changes nothing."""
+    hs, dev, orc = scenes(name)
+    n = hs.desc.contents.options.numRays
+    full, st = dev.render(seed=11)
+    cut = max(1, n // 3)
+    part, sa = dev.render(seed=11, first_sample=0, sample_count=cut, samples_per_pass=1)
+    rest, sb = dev.render(seed=11, first_sample=cut, keep_accumulator=True)
+    assert sa.cameraSamples + sb.cameraSamples == st.cameraSamples
+    assert np.array_equal(rest.view(np.uint32), full.view(np.uint32))
+    opart, _ = orc.render(seed=11, first_sample=0, sample_count=cut)
+    assert np.array_equal(part[..., 3], opart[..., 3]) and psnr(part[..., :3], opart[..., :3]) >= PSNR_MIN_DB
+    with pytest.raises(RuntimeError):
+        dev.render(seed=11, first_sample=0, sample_count=1, keep_accumulator=True, part_index=1, part_count=2)
+    same, ss = dev.render(seed=11, adaptive_threshold=0.5, adaptive_batch=2, adaptive_min_samples=n)  # no pixel may stop before the end
+    assert ss.cameraSamples == st.cameraSamples and np.array_equal(same.view(np.uint32), full.view(np.uint32))
+    few, sf = dev.render(seed=11, adaptive_threshold=0.1, adaptive_batch=2)
+    ofew, osf = orc.render(seed=11, adaptive_threshold=0.1, adaptive_batch=2)
+    assert sf.cameraSamples < st.cameraSamples
+    assert abs(int(sf.cameraSamples) - int(osf.cameraSamples)) <= 0.01 * osf.cameraSamples
+    assert psnr(few[..., :3], ofew[..., :3]) >= PSNR_MIN_DB
+
+
 def _unit_or_longer_rays(n, seed):
     rng = np.random.default_rng(seed)
     o = (rng.normal(size=(n, 3)) * np.array([4.0, 2.4, 4.0]) + np.array([0, 0.3, -3])).astype(np.float32)

@@ -259,6 +259,31 @@ def _declared(header):
     return sorted(set(re.findall(r"\b(rth?_[a-z0-9_]+)\s*\(", text)))
 
 
+def test_oracle_progressive_and_adaptive_sampling(scene_path):
+    """The extended sample loop (RtRenderParams.firstSample / sampleCount / keepAccumulator and adaptive*) in the CPU
+    restatement: sample windows added up give the frame of one call bit for bit; the estimate after a partial window is
+    the frame of a scene with that many samples except for alpha's denominator; adaptive sampling that may not stop before the
+    last sample changes nothing, and with a real threshold takes fewer samples and stays close to the full frame."""
+    hs = capi.HostScene.load(scene_path("mesh1k_gi")).build()
+    orc = oracle_scene(hs.desc)
+    full, st = orc.render(seed=7)
+    n = hs.desc.contents.options.numRays
+    assert n >= 4
+    a, sa = orc.render(seed=7, first_sample=0, sample_count=n // 2)
+    b, sb = orc.render(seed=7, first_sample=n // 2, keep_accumulator=True)
+    assert sa.cameraSamples + sb.cameraSamples == st.cameraSamples
+    assert np.array_equal(b.view(np.uint32), full.view(np.uint32))
+    assert not np.array_equal(a.view(np.uint32), full.view(np.uint32))
+    with pytest.raises(RuntimeError):
+        orc.render(seed=7, first_sample=n)
+    same, ss = orc.render(seed=7, adaptive_threshold=0.5, adaptive_batch=2, adaptive_min_samples=n)  # no pixel may stop before the end
+    assert ss.cameraSamples == st.cameraSamples and np.array_equal(same.view(np.uint32), full.view(np.uint32))
+    few, sf = orc.render(seed=7, adaptive_threshold=0.2, adaptive_batch=2)
+    assert sf.cameraSamples < st.cameraSamples
+    assert psnr(few[..., :3], full[..., :3]) >= 20.0
+    orc.close()
+
+
 REF_BINDING = os.path.join(REPO, "oracle", "_ref", "ref_binding")
 
 

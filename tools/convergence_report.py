@@ -27,9 +27,9 @@ dev = capi.device_scene(hs.desc)
 o = hs.desc.contents.options
 
 
-def frame(spp, seed):
+def frame(spp, seed, **kw):
     dev.set_view(options=capi.RtOptions(o.width, o.height, o.bias, o.exposure, o.maxBounces, spp, o.fisheye, o.focus, o.lens))
-    img, st = dev.render(seed=seed)
+    img, st = dev.render(seed=seed, **kw)
     return img[..., :3].astype(np.float64), st
 
 
@@ -42,5 +42,23 @@ for spp in (1, 4, 16, 64, 256, 1024):
     mse = float(((img - ref) ** 2).mean())
     rows.append({"spp": spp, "rmse": round(mse ** 0.5, 5), "psnr_db": round(10 * np.log10(1.0 / mse), 2), "ms": round(st.msTotal, 2),
                  "mrays_per_s": round((st.raysClosest + st.raysAny) / st.msTotal / 1e3, 1)})
+# adaptive sampling (up to 1024 samples per pixel, stop per pixel by the standard error of its luminance): what a given
+# error costs in samples compared with the uniform levels above
+adaptive = []
+for thr in (0.1, 0.05, 0.02, 0.01):
+    img, st = frame(min(1024, args.ref_spp // 2), 99, adaptive_threshold=thr, adaptive_batch=16)
+    mse = float(((img - ref) ** 2).mean())
+    adaptive.append({"threshold": thr, "mean_spp": round(st.cameraSamples / (o.width * o.height), 1), "rmse": round(mse ** 0.5, 5),
+                     "psnr_db": round(10 * np.log10(1.0 / mse), 2), "ms": round(st.msTotal, 2), "passes": st.passes})
+# progressive rendering: the estimate after 16, 64, 256 samples of ONE 256-sample frame built up by windows
+prog = []
+first = 0
+for upto in (16, 64, 256):
+    dev.set_view(options=capi.RtOptions(o.width, o.height, o.bias, o.exposure, o.maxBounces, 256, o.fisheye, o.focus, o.lens))
+    img, st = dev.render(seed=5, first_sample=first, sample_count=upto - first, keep_accumulator=first > 0)
+    mse = float(((img[..., :3].astype(np.float64) - ref) ** 2).mean())
+    prog.append({"samples_so_far": upto, "rmse": round(mse ** 0.5, 5), "ms_this_window": round(st.msTotal, 2)})
+    first = upto
+print(json.dumps({"adaptive": adaptive, "progressive": prog}))
 print(json.dumps({"scene": f"README stand-in {o.width}x{o.height}, {hs.desc.contents.numPrims} objects", "reference_spp": args.ref_spp,
                   "levels": rows}))
