@@ -454,27 +454,50 @@ struct PixelAcc {
 // appended to `nextActive`.
 __global__ __launch_bounds__(kBlock) void k_accumulate(PathBuf B, PixelAcc A, int32_t nPix, int32_t sppThis, float threshold, int32_t minSamples,
                                                        int32_t maxSamples, int32_t *nextActive, uint32_t *nextCount) {
-  int32_t p = blockIdx.x * kBlock + threadIdx.x;
+  // A pixel's samples are neighbours in memory (slot = pixel position * spp + sample) and a lane sums ONE pixel in sample
+  // order, so a wavefront reads its 64 pixels' samples through LDS: chunks of kChunk samples per pixel are loaded with
+  // consecutive lanes on consecutive samples (128-byte runs) and read back transposed, one pixel per lane.
+  constexpr int kChunk = 8, kRow = 65;  // 65: rows of 64 float4 plus one of padding, so the transposed writes spread over the banks
+  __shared__ float4 tile[kBlock / 64][kChunk * kRow];
+  const int32_t p = blockIdx.x * kBlock + threadIdx.x;
+  const int32_t lane = (int32_t)__lane_id(), wave = threadIdx.x >> 6;
+  const int32_t waveBase = p - lane;
+  const bool valid = p < nPix;
   bool goesOn = false;
   int32_t fp = 0;
-  if (p < nPix) {
+  RGBA avg = rgba(0, 0, 0, 0);
+  int hits = 0;
+  float s1 = 0.0f, s2 = 0.0f;
+  if (valid) {
     fp = B.active ? B.active[p] : p;
-    RGBA avg = rgba(A.sum[fp]);
-    int hits = A.hits[fp];
-    float s1 = 0.0f, s2 = 0.0f;
+    avg = rgba(A.sum[fp]);
+    hits = A.hits[fp];
     if (threshold > 0) { s1 = A.lumSum[fp]; s2 = A.lumSqSum[fp]; }
-    for (int s = 0; s < sppThis; ++s) {
-      RGBA color = rgba(B.L[(int64_t)p * sppThis + s]);
-      if (hasNaN(color) == false && color.a != 0) {
-        addAssign(avg, color);
-        ++hits;
-        if (threshold > 0) {
-          float y = (0.2126f * color.r + 0.7152f * color.g) + 0.0722f * color.b;
-          s1 += y;
-          s2 += y * y;
+  }
+  for (int s0 = 0; s0 < sppThis; s0 += kChunk) {
+    const int ch = min(kChunk, sppThis - s0);
+    for (int e = lane; e < 64 * ch; e += 64) {
+      const int px = e / ch, sm = e - px * ch;
+      if (waveBase + px < nPix) tile[wave][sm * kRow + px] = B.L[(int64_t)(waveBase + px) * sppThis + s0 + sm];
+    }
+    __syncthreads();
+    if (valid) {
+      for (int sm = 0; sm < ch; ++sm) {
+        RGBA color = rgba(tile[wave][sm * kRow + lane]);
+        if (hasNaN(color) == false && color.a != 0) {
+          addAssign(avg, color);
+          ++hits;
+          if (threshold > 0) {
+            float y = (0.2126f * color.r + 0.7152f * color.g) + 0.0722f * color.b;
+            s1 += y;
+            s2 += y * y;
+          }
         }
       }
     }
+    __syncthreads();
+  }
+  if (valid) {
     const int32_t taken = A.taken[fp] + sppThis;
     A.sum[fp] = f4(avg);
     A.hits[fp] = hits;

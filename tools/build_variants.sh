@@ -7,7 +7,7 @@ pids=()
 for spec in "$@"; do
   name=${spec%%=*}; flags=${spec#*=}
   ( /opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize $flags -Iinclude -Iraytracer_amd/csrc \
-      -shared raytracer_amd/csrc/rt_device.hip -o variants/lib_$name.so 2> variants/$name.log || echo "build of $name failed" ) &
+      -shared raytracer_amd/csrc/rt_device.hip raytracer_amd/csrc/rt_bvh_build.hip -o variants/lib_$name.so 2> variants/$name.log || echo "build of $name failed" ) &
   pids+=($!)
   if (( ${#pids[@]} >= 6 )); then wait "${pids[0]}"; pids=("${pids[@]:1}"); fi
 done
