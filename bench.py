@@ -235,24 +235,43 @@ def main():
     lu_i, lu_p = ((cst.laneUseInnerExtend, cst.laneUsePrimExtend) if kname == "k_extend" else (cst.laneUseInnerShadow, cst.laneUsePrimShadow))
     lane_use = (inner + prims) / (inner / lu_i + prims / lu_p) if lu_i > 0 and lu_p > 0 else None
     avg_ms = kms / max(1, klaunch)
-    L1_PEAK = 1.45  # L1 accesses per clock per CU, every access a hit on a different line (tools/micro/l1_access_probe.hip)
+    # Roofs measured on this GPU with tools/micro/l1_access_probe.hip (profiles/r02_micro_probes.txt): scattered 16-byte
+    # accesses that all hit the L1, and scattered 64-byte records served by the L2 / by the Infinity Cache.
+    L1_PEAK = 1.46          # L1 accesses per clock per CU
+    L2_RECORDS_PER_S = 209e9
+    IC_RECORDS_PER_S = 58e9
+    l1 = prof.get("l1_access_busy") if prof else None
+    mem_model = None
+    if prof and "l2_read_requests_per_launch" in prof and "l2_misses_per_launch" in prof:
+        # time the L1 misses of one launch would take at the probe's rates: hits in L2 + fetches from beyond it
+        t_min = ((prof["l2_read_requests_per_launch"] - prof["l2_misses_per_launch"]) / L2_RECORDS_PER_S
+                 + prof["l2_misses_per_launch"] / IC_RECORDS_PER_S)
+        mem_model = {"l2_read_requests_per_launch": prof["l2_read_requests_per_launch"], "l2_misses_per_launch": prof["l2_misses_per_launch"],
+                     "l2_hit": prof.get("l2_hit"), "time_at_probe_rates_ms": round(t_min * 1e3, 2),
+                     "frac": round(t_min / (prof["trace_avg_us"] * 1e-6), 4),
+                     "unit": "launch time the L1 misses alone would need at the measured scattered-record rates of L2 (209 G/s) and "
+                             "Infinity Cache (58 G/s), over the launch time"}
     roofline = {
-        "bound": "valu_issue", "kernel": kname, "unit": "fraction of vector-ALU issue cycles in use (SQ_ACTIVE_INST_VALU)", "peak": 1.0,
-        "achieved": prof.get("valu_busy") if prof else None,
-        "frac": prof.get("valu_busy") if prof else None,
-        "useful_frac": round(prof["valu_busy"] * lane_use, 4) if prof and prof.get("valu_busy") and lane_use else None,
+        # The traversal kernels gather one 64-byte node or 48-byte object record per lane and step, every lane elsewhere. What
+        # they saturate is the rate at which a CU's vector L1 / texture addresser takes scattered lane accesses: adding one
+        # load per node step slows them by 12-28 %, adding 40 ALU instructions per step by 5 % (profiles/README.md).
+        "bound": "l1_scattered_access", "kernel": kname,
+        "unit": "L1 accesses per clock per CU (TCP_TOTAL_CACHE_ACCESSES_sum / 256 CUs / GPU cycles), one per lane and load instruction",
+        "peak": L1_PEAK, "achieved": l1, "frac": round(l1 / L1_PEAK, 4) if l1 else None,
+        "ta_busy": prof.get("ta_busy") if prof else None,
         "lane_use": round(lane_use, 4) if lane_use else None,
         "lane_use_by_loop": {"extend_inner": round(cst.laneUseInnerExtend, 3), "extend_prim": round(cst.laneUsePrimExtend, 3),
                              "shadow_inner": round(cst.laneUseInnerShadow, 3), "shadow_prim": round(cst.laneUsePrimShadow, 3)},
-        "l1": ({"accesses_per_clk_per_cu": round(prof["l1_access_busy"], 4), "peak": L1_PEAK,
-                "frac": round(prof["l1_access_busy"] / L1_PEAK, 4)} if prof and "l1_access_busy" in prof else None),
+        "valu": ({"busy": prof.get("valu_busy"), "unit": "SQ_ACTIVE_INST_VALU * 4 / 1024 SIMDs / GPU cycles",
+                  "instr_per_ray": round(prof["valu_instr_per_launch"] / (krays / max(1, klaunch)), 1) if "valu_instr_per_launch" in prof else None}
+                 if prof else None),
+        "l2_and_beyond": mem_model,
         "hbm": ({"bound": "hbm", "achieved": round(prof["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": round(prof["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                 "traffic": prof["hbm_bytes_per_launch"], "traffic_unit": "bytes per launch (FETCH_SIZE as counted for scattered 64-byte "
-                 "records, see tools/pmc_traffic.py, + WRITE_SIZE)"} if prof else None),
+                 "traffic": prof["hbm_bytes_per_launch"], "traffic_unit": "bytes per launch leaving the L2 (FETCH_SIZE as counted for scattered "
+                 "64-byte records, see tools/pmc_traffic.py, + WRITE_SIZE)"} if prof else None),
         "traffic": prof["hbm_bytes_per_launch"] if prof else None,
-        "profile": ({"file": "profiles/pmc_traffic.json", "avg_launch_ms": round(prof.get("trace_avg_us", 0) / 1e3, 4),
-                     "valu_instr_per_ray": round(prof["valu_instr_per_launch"] / (krays / max(1, klaunch)), 1) if "valu_instr_per_launch" in prof else None}
+        "profile": ({"file": "profiles/pmc_traffic.json", "avg_launch_ms": round(prof.get("trace_avg_us", 0) / 1e3, 4)}
                     if prof else "no counters for this workload / these kernel sources: rerun tools/profile_on_box.sh"),
         # what a cache-less machine would have to fetch: every node visit 64 B, every object test 48 B (served by L1/L2 here)
         "algorithmic_cache_bytes_per_launch": int(krays * kb / max(1, klaunch)),
@@ -314,8 +333,8 @@ def main():
         "mrays_bvh_traversed_per_s": round(traversed_total / elapsed / 1e6, 2),
         "rays_per_frame": int(rays_total / args.steps),
         "rays_bvh_traversed_per_frame": int(traversed_total / args.steps),
-        # visibility queries the reference traces and this library answers without a traversal (zero contribution, or a
-        # plane alone decides); `value` counts traversed queries only
+        # visibility queries the reference traces and this library answers without a BVH traversal: zero contribution
+        # (not part of `value`), or a plane alone decides (part of `value`, see value_definition)
         "rays_skipped_per_frame": int(sum(s.raysSkipped for s in stats) / args.steps),
         "rays_plane_answered_per_frame": int(sum(s.raysPlaneAnswered for s in stats) / args.steps),
         "reference_queries_per_frame": int((traversed_total + sum(s.raysSkipped for s in stats)) / args.steps) if world == 1 else None,

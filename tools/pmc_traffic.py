@@ -11,8 +11,11 @@ Units and corrections:
     streaming kernels (STREAMING below); the traversal kernels use the counter as it is.
   * SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs, GRBM_GUI_ACTIVE cycles summed over the 8 XCDs:
     valu_busy = SQ_ACTIVE_INST_VALU * 4 / 1024 / (GRBM_GUI_ACTIVE / 8).
-  * TCP_TOTAL_CACHE_ACCESSES_sum is summed over the 256 L1 caches, each of which serves one access (one cache line of
-    one instruction) per cycle: l1_access_busy = accesses / 256 / (GRBM_GUI_ACTIVE / 8).
+  * TCP_TOTAL_CACHE_ACCESSES_sum is summed over the 256 L1 caches and counts one access per lane and load instruction
+    for scattered loads (tools/micro/l1_access_probe.hip under the same counter: 4.00 per 64-byte record read with four
+    16-byte loads): l1_access_busy = accesses / 256 / (GRBM_GUI_ACTIVE / 8), in accesses per clock and CU; the probe
+    reaches 1.46 with every access a hit. ta_busy = TA_TA_BUSY_sum / 256 / cycles.
+  * TCP_TCC_READ_REQ_sum counts the L1 misses: 1.05 per scattered 64-byte record in the probe.
 `source_sha1` is the hash of the kernel sources the profiled library was built from: bench.py reports these figures only
 while the sources in the tree still have that hash."""
 import hashlib
@@ -103,6 +106,10 @@ def main():
                 e["l1_access_busy"] = round(c_["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256 / cyc_c, 4)
             if "TA_TA_BUSY_sum" in c_:
                 e["ta_busy"] = round(c_["TA_TA_BUSY_sum"] / 256 / cyc_c, 4)
+            if "TCP_TCC_READ_REQ_sum" in c_:
+                e["l2_read_requests_per_launch"] = int(c_["TCP_TCC_READ_REQ_sum"])  # L1 misses: one per 64-byte record fetched from L2
+            if "TCC_MISS_sum" in c_:
+                e["l2_misses_per_launch"] = int(c_["TCC_MISS_sum"])
             if c_.get("TCC_HIT_sum") is not None and c_.get("TCC_MISS_sum") is not None and c_["TCC_HIT_sum"] + c_["TCC_MISS_sum"] > 0:
                 e["l2_hit"] = round(c_["TCC_HIT_sum"] / (c_["TCC_HIT_sum"] + c_["TCC_MISS_sum"]), 4)
         res["kernels"][k] = e

@@ -16,3 +16,7 @@ timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_IN
 timeout -s KILL 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_TA_BUSY_sum GRBM_GUI_ACTIVE -d "$OUT/pmc_cache" -o cache -- $BENCH > "$OUT/pmc_cache.log" 2>&1 || { echo "cache pass failed"; tail -5 "$OUT/pmc_cache.log"; exit 1; }
 find "$OUT" -name '*.csv' | head -40
 du -sh "$OUT"
+# the record-fetch probe under the same cache counters: how many L1->L2 requests one scattered 64-byte record costs, and
+# the rates it reaches un-profiled (the roofs bench.py prices the traversal kernels against)
+timeout -s KILL 120 $ROOT/tools/micro/l1_access_probe > "$OUT/record_fetch_probe.txt" 2>&1 || echo "probe failed"
+timeout -s KILL 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum -d "$OUT/pmc_probe" -o probe -- $ROOT/tools/micro/l1_access_probe > "$OUT/pmc_probe.log" 2>&1 || echo "probe counter pass failed"
