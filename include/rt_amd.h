@@ -208,7 +208,7 @@ int rt_trace_primary(RtScene *scene, int32_t x0, int32_t y0, int32_t w, int32_t 
 
 /* rt_trace_primary for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc). It has no counterpart in the reference. Same arguments, same results bit for bit;
- * the queue ticket and the device-side staging of ids and t live in a static device array of the library (32 MiB + 256 B
+ * the queue ticket and the device-side staging of ids and t live in a static device array of the library (32 MiB + 1 KiB
  * per GPU, held from library load to process exit) instead of memory the scene allocates, and the call makes no
  * hipMalloc / hipFree. Limits: w * h <= rt_trace_primary_static_max_pixels() (4 Mi pixels; larger rectangles are
  * refused with RT_ERR_INVALID); all scenes on one GPU share that GPU's array, so calls that overlap in time on one GPU

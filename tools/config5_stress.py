@@ -83,6 +83,19 @@ def main():
             "random_equal": bool(all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(g, r))),
             "random_any_equal": bool(np.array_equal(dev.trace_any(o, dr), orc.trace_any(o, dr)))}
         orc.close()
+    # the same scene with the tree built on the GPU (RtSceneDesc.nodes = NULL): build time, frame time, t bits of the primary hits
+    t0 = time.time()
+    lb = capi.device_scene(hs.desc, build_on_device=True)
+    t_create = time.time() - t0
+    lb.render(download=False)
+    _, sl = lb.render(download=False)
+    y0 = args.height // 2 - max(1, args.check_rows) // 2
+    gi, gt = dev.trace_primary(0, y0, args.width, max(1, args.check_rows))
+    li, lt = lb.trace_primary(0, y0, args.width, max(1, args.check_rows))
+    out["device_bvh"] = {"build_ms": round(lb.bvh_build_ms(), 2), "scene_create_s": round(t_create, 2), "ms_frame": round(sl.msTotal, 2),
+                         "primary_t_bits_equal_to_host_tree": bool(np.array_equal(gt.view(np.uint32), lt.view(np.uint32))),
+                         "primary_ids_differing": int((gi != li).sum())}
+    lb.close()
     print(json.dumps(out), flush=True)
 
 

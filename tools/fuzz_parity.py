@@ -108,6 +108,18 @@ def detail(hs, dev, orc, o, d):
         print(f"   ray {i}: o {o[i].tolist()} d {d[i].tolist()} gpu {ga[i]} cpu {ra[i]} closest gpu id {g[0][i]} t {g[1][i]!r}")
     gi, gt = dev.trace_primary(); oi, ot = orc.trace_primary()
     print(f"primary: {(gi != oi).sum()} ids, {(gt.view(np.uint32) != ot.view(np.uint32)).sum()} t differ")
+    # the frame: which pixels differ, and from which path length on (a path that branched the other way on a last-bit
+    # difference of a transcendental shows as agreement up to some number of bounces and a jump after it)
+    op = dsc.options
+    for mb in range(1, op.maxBounces + 1):
+        v = capi.RtOptions(op.width, op.height, op.bias, op.exposure, mb, op.numRays, op.fisheye, op.focus, op.lens)
+        dev.set_view(options=v); orc.set_view(options=v)
+        img, st = dev.render(seed=int(os.environ.get("FUZZ_FRAME_SEED", "0"))); ref, ost = orc.render(seed=int(os.environ.get("FUZZ_FRAME_SEED", "0")))
+        diff = np.abs(img[..., :3] - ref[..., :3]).max(-1)
+        ys, xs = np.nonzero(diff > 1e-6)
+        print(f"maxBounces {mb}: {ys.size} pixels differ by > 1e-6 (max {diff.max():.3g}), rays gpu {st.raysClosest + st.raysAny + st.raysSkipped} cpu {ost.raysClosest + ost.raysAny}")
+        for y, x in list(zip(ys, xs))[:6]:
+            print(f"   pixel ({x},{y}): gpu {img[y, x].tolist()} cpu {ref[y, x].tolist()}")
 
 
 def main():
