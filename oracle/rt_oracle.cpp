@@ -846,6 +846,9 @@ const char *rto_version(void) { return "rt_oracle 1 (CPU restatement, test infra
 
 RtoScene *rto_scene_create(const RtSceneDesc *d, int /*device*/) {
   if (!d) { fail("null desc"); return nullptr; }
+  // The restatement walks the reference's tree only: a description without nodes asks for the HIP library's own
+  // device-side BVH build, which has no counterpart in the reference.
+  if (d->numPrims > 0 && (!d->nodes || d->numNodes <= 0)) { fail("the CPU restatement needs the host-built BVH nodes"); return nullptr; }
   auto s = std::make_unique<RtoScene>();
   s->nodes.assign(d->nodes, d->nodes + d->numNodes);
   s->numPrims = d->numPrims;

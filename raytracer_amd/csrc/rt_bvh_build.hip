@@ -134,11 +134,14 @@ __device__ __forceinline__ Box objectBox(const float *aabbMin, const float *aabb
   for (int k = 0; k < 3; ++k) { b.mn[k] = aabbMin[3 * (int64_t)obj + k]; b.mx[k] = aabbMax[3 * (int64_t)obj + k]; }
   return b;
 }
-// std::min / std::max semantics, as BVH::updateNodeBounds (src/acceleration/BVH.cpp:72-90) unites boxes
+// Union of two boxes (BVH::updateNodeBounds, src/acceleration/BVH.cpp:72-90) with fminf / fmaxf, which return the other
+// operand when one is NaN: an object with NaN coordinates (a degenerate triangle) cannot be hit anyway and must not turn
+// the boxes of its ancestors into NaN, which would hide the regular objects below them. (The reference's std::min /
+// std::max chain keeps or drops a NaN depending on the order of the operands; its tree can lose such subtrees.)
 __device__ __forceinline__ Box unite(const Box &a, const Box &b) {
   Box r;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { r.mn[k] = b.mn[k] < a.mn[k] ? b.mn[k] : a.mn[k]; r.mx[k] = a.mx[k] < b.mx[k] ? b.mx[k] : a.mx[k]; }
+  for (int k = 0; k < 3; ++k) { r.mn[k] = fminf(a.mn[k], b.mn[k]); r.mx[k] = fmaxf(a.mx[k], b.mx[k]); }
   return r;
 }
 

@@ -351,6 +351,64 @@ def test_bvh_built_on_the_device(name, scenes, scene_path):
         lb.close(); raw.close()
 
 
+def test_device_bvh_build_on_degenerate_input():
+    """Inputs that stress the radix tree: thousands of objects at the same place (one Morton code: the tree is decided by
+    position alone), one, two and five objects, a mesh whose triangles are all NaN among regular spheres. Hits through the
+    device-built tree equal hits through the host-built tree (t bits). A description without nodes AND without boxes is
+    refused, and so is a description without nodes handed to the CPU restatement."""
+    rng = np.random.default_rng(5)
+
+    def scene(kind):
+        hs = capi.HostScene.new(64, 48)
+        m = hs.add_material(capi.RT_MAT_DEFAULT)
+        if kind == "same":
+            for _ in range(3000):
+                hs.add_sphere((0.2, 0.1, -3.0), 0.7, material=m)
+        elif kind == "nan":
+            hs.add_mesh(np.zeros((3, 3)), None, np.array([[0, 1, 2]] * 40), material=m)  # zero extent: every triangle is NaN
+            for c in rng.normal(size=(300, 3)):
+                hs.add_sphere(tuple(c * [1.5, 1.0, 0.5] + [0, 0, -3]), 0.15, material=m)
+        else:
+            for c in rng.normal(size=({"one": 1, "two": 2, "five": 5, "soup": 4000}[kind], 3)):
+                hs.add_sphere(tuple(c * [1.5, 1.0, 0.5] + [0, 0, -3]), 0.08, material=m)
+        hs.add_light(capi.RT_LIGHT_POINT, color=(5, 5, 5, 1), v=(0, 3, 0))
+        hs.set_camera(); hs.set_options(64, 48, numRays=1)
+        return hs.build()
+
+    for kind in ("same", "one", "two", "five", "soup", "nan"):
+        hs = scene(kind)
+        ref = capi.device_scene(hs.desc)
+        lb = capi.device_scene(hs.desc, build_on_device=True)
+        a, b = ref.trace_primary(), lb.trace_primary()
+        o, d = _unit_or_longer_rays(20_000, 9)
+        ra, rb = ref.trace_closest(o, d), lb.trace_closest(o, d)
+        if kind == "nan":
+            # NaN boxes: the reference's min/max chain lets a NaN object hide regular objects that share a subtree with
+            # it (the host build reproduces that); the device build keeps NaN out of the ancestors' boxes. Every hit of
+            # the host tree is a hit of the device tree with the same t; the device tree may see more.
+            for x, y in ((a[1], b[1]), (ra[1], rb[1])):
+                hit = np.isfinite(x)
+                assert np.array_equal(x[hit].view(np.uint32), y[hit].view(np.uint32))
+            assert not (ref.trace_any(o, d) & ~lb.trace_any(o, d)).any()
+        else:
+            assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), kind
+            if kind != "same":  # identical objects tie everywhere: which one is reported is the tree's choice
+                assert (a[0] != b[0]).mean() <= 0.01, kind
+            assert np.array_equal(ra[1].view(np.uint32), rb[1].view(np.uint32)), kind
+            assert np.array_equal(ref.trace_any(o, d), lb.trace_any(o, d)), kind
+        ref.close(); lb.close()
+    hs = scene("five")
+    C = capi.C
+    d = capi.RtSceneDesc()
+    C.pointer(d)[0] = hs.desc.contents
+    d.nodes = None; d.numNodes = 0
+    with pytest.raises(RuntimeError, match="restatement needs"):
+        oracle_scene(C.pointer(d))
+    d.primAabbMin = None
+    with pytest.raises(RuntimeError, match="primAabbMin"):
+        capi.RenderScene(capi.load_device_library(), "rt_", C.pointer(d), 0)
+
+
 REF_BINDING = os.path.join(REPO, "oracle", "_ref", "ref_binding")
 
 
