@@ -21,6 +21,6 @@ for mb in [int(x) for x in os.environ.get('PROBE_BOUNCES', '1,2,4').split(',')]:
     _, st = dev.render(download=False)
     _, c = dev.render(download=False, collect_counters=True)
     print(f"maxBounces={mb}: extend {st.raysExtend / st.msExtend / 1e3:.0f} Mrays/s ({st.msExtend:.2f} ms), shadow "
-          f"{st.raysShadow / st.msShadow / 1e3:.0f} Mrays/s ({st.msShadow:.2f} ms), shade {st.msShade:.2f} ms | lane use extend inner "
+          f"{st.raysShadow / st.msShadow / 1e3:.0f} Mrays/s ({st.msShadow:.2f} ms), shade {st.msShade:.2f} ms, direct {st.msDirect:.2f} ms, resolve {st.msResolve:.2f} ms, total {st.msTotal:.2f} ms | lane use extend inner "
           f"{c.laneUseInnerExtend:.3f} prim {c.laneUsePrimExtend:.3f}, shadow inner {c.laneUseInnerShadow:.3f} prim {c.laneUsePrimShadow:.3f} | "
           f"inner/ray ext {c.innerExtend / c.raysExtend:.1f} sh {c.innerShadow / c.raysShadow:.1f}, prim/ray ext {c.primExtend / c.raysExtend:.1f} sh {c.primShadow / c.raysShadow:.1f}")
