@@ -112,6 +112,31 @@ RT_DEV void slabFinite(V3 o, V3 inv, float mnx, float mny, float mnz, float mxx,
   tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx_near, tx_far), __builtin_fmaxf(ty_near, ty_far)), __builtin_fmaxf(tz_near, tz_far));
 }
 
+// The closest plane along a ray (origin o, normalised direction nd). The reference tests the planes after the BVH
+// (src/scene/raytracer.cpp:174-196), each with Plane::intersect (src/scene/Object.cpp:133-141), keeping the first plane in
+// scene order that reaches the smallest t; that plane does not depend on the BVH part of the query. Returns the number of
+// planes tested.
+RT_DEV int closestPlane(const DevScene &S, V3 o, V3 nd, float &tPlane, int32_t &plane) {
+  tPlane = kInf; plane = -1;
+  for (int32_t k = 0; k < S.numPlanes; ++k) {
+    const DevPlane &pl = S.planes[k];
+    V3 pn = v3(pl.normal), pp = v3(pl.point);
+    float t = dot(pp - o, pn) / dot(nd, pn);
+    if (t < 0) continue;
+    if (t < tPlane) { tPlane = t; plane = k; }
+  }
+  return S.numPlanes;
+}
+// A visibility query asks a yes/no question that a plane alone can settle: findAnyObject is non-null as soon as any plane
+// is hit (src/scene/raytracer.cpp:177-183), and a point-light query is in shadow as soon as a plane lies nearer than the
+// bulb (the closest hit overall is then nearer still; src/scene/Object.cpp:18-25). Such a query needs no traversal.
+RT_DEV bool planeSettlesVisibility(bool pointLight, V3 o, V3 nd, float bulbDist, float tPlane, int32_t plane) {
+  if (plane < 0) return false;
+  if (!pointLight) return true;
+  V3 hp = tPlane * nd + o;
+  return magnitude(o - hp) < bulbDist;
+}
+
 #ifndef RT_CHUNK_MAX
 #define RT_CHUNK_MAX 256
 #endif
@@ -198,6 +223,7 @@ constexpr int kMaxTreeDepth = kMaxStack;
 //   uint32_t total()                                                       number of queries in the queue
 //   uint32_t fetch(uint32_t idx, V3 &o, V3 &d, int &mode, float &bulbDist) load query idx, return a tag for store()
 //   void store(uint32_t tag, HitRec hit, bool occluded, V3 o, V3 nd)       deliver its result
+//   static constexpr bool kPlanesDone                                      the planes were tested before the query was queued
 //
 // LDS the caller provides: ldsStack = K * BLOCK uint2 (stack columns), ldsPool = (BLOCK / 64) * kPoolFields * kPoolSlots dwords.
 
@@ -408,28 +434,16 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
         qitem = src.fetch(idx, qo, d, qmode, qbulb);
         if (!(RUNTIME_MODE && qmode == TRAV_SKIP)) {
           qnd = normalized(d);
-          // Planes first. The reference tests them after the BVH (src/scene/raytracer.cpp:174-196), each with
-          // Plane::intersect (src/scene/Object.cpp:133-141), keeping the first plane in scene order that reaches the
-          // smallest t; that plane does not depend on the BVH part, so it is found here and compared at the end.
-          // A visibility query asks a yes/no question that a plane alone can settle: findAnyObject is non-null as soon
-          // as any plane is hit (:177-183), and a point-light query is in shadow as soon as a plane lies nearer than
-          // the bulb (the closest hit overall is then nearer still; src/scene/Object.cpp:18-25). Such a query needs no
-          // traversal at all; it is counted apart (TravCounters::planeAnswered*).
-          for (int32_t k = 0; k < S.numPlanes; ++k) {
-            if (COUNT) ++tc.planes;
-            const DevPlane &pl = S.planes[k];
-            V3 pn = v3(pl.normal), pp = v3(pl.point);
-            float t = dot(pp - qo, pn) / dot(qnd, pn);
-            if (t < 0) continue;
-            if (t < qtPlane) { qtPlane = t; qplane = k; }
-          }
+          // Planes first: the closest plane is found here and compared with the BVH's answer at the end. A visibility
+          // query that a plane alone settles never reaches a lane; it is counted apart (TravCounters::planeAnswered*).
+          // A source that has dealt with the planes itself (Source::kPlanesDone) only hands over queries no plane settles.
           bool planeAnswers = false;
-          if (RUNTIME_MODE && qplane >= 0) {
-            if (qmode == TRAV_ANY) {
-              planeAnswers = true; ++tc.planeAnsweredAny;
-            } else if (qmode == TRAV_POINT_LIGHT) {
-              V3 hp = qtPlane * qnd + qo;
-              if (magnitude(qo - hp) < qbulb) { planeAnswers = true; ++tc.planeAnsweredPoint; }
+          if (!Source::kPlanesDone) {
+            const int tested = closestPlane(S, qo, qnd, qtPlane, qplane);
+            if (COUNT) tc.planes += (uint32_t)tested;
+            if (RUNTIME_MODE && qmode != TRAV_CLOSEST && planeSettlesVisibility(qmode == TRAV_POINT_LIGHT, qo, qnd, qbulb, qtPlane, qplane)) {
+              planeAnswers = true;
+              if (qmode == TRAV_POINT_LIGHT) ++tc.planeAnsweredPoint; else ++tc.planeAnsweredAny;
             }
           }
           if (planeAnswers) {

@@ -77,6 +77,10 @@ struct PathBuf {
   float4 *envWi;   // [numEnvLights][P] hemisphere direction drawn for each environment light
   float4 *lightC;  // [numLights][P] what each light contributes if it turns out to be visible
   uint32_t *qA, *qB, *qHit;
+  // [numLights][rowsCap] what k_shade decided about the visibility query of each queue position, 64 positions per entry:
+  // bit p of {x, y} (low, high word) and of {z, w} form a 2-bit code per position (ShadowCode)
+  uint4 *shadowCode;
+  int32_t rowsCap;
   Counts *counts;
   int32_t P, npix;
   int32_t spp;  // samples per pixel in this pass; path slot = pixel position * spp + sample, so a pixel's samples are neighbours
@@ -191,6 +195,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DevScene S, PathBuf B, const 
 
 // ---------------------------------------------------------------------------------------------------- k_extend
 struct ExtendSource {
+  static constexpr bool kPlanesDone = false;
   const PathBuf &B;
   const uint32_t *queue;
   RT_DEV uint32_t total() const { return B.counts->nActive; }
@@ -219,6 +224,14 @@ __global__ RT_TRAV_ATTR void k_extend(DevScene S, PathBuf B, const uint32_t *que
 }
 
 // ---------------------------------------------------------------------------------------------------- k_shade
+// What k_shade decides about the visibility query of (queue position, light), two bits per query:
+enum ShadowCode {
+  SHADOW_NONE = 0,    // no query: the path missed, or the position is beyond the queue
+  SHADOW_TRACE = 1,   // k_shadow has to trace it
+  SHADOW_PLANE = 2,   // one of the scene's planes alone settles it: hidden, contribution already replaced
+  SHADOW_ZERO = 3     // the unshadowed contribution is exactly (0, 0, 0): visible or not, it adds the same nothing
+};
+
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 5
 #endif
@@ -227,6 +240,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   bool isHit = false, continues = false;
   uint32_t slot = 0;
+  // state of a hit that the three parts below share
+  Rng rng{};
+  V3 nd = v3(0, 0, 0), point = nd, normal = nd, outNormal = nd, biased = nd;
+  RGBA beta = rgba(0, 0, 0, 0), objColor = beta;
+  int32_t matIdx = 0;
+  // ------------------------------------------------------------------ part 1: the hit (or the miss)
   if (i < B.counts->nActive) {
     slot = queue[i];
     // Loads that depend only on the path slot, then loads that depend only on the object, each group issued together:
@@ -236,7 +255,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
     float t = B.hitT[slot];
     // the path's random stream is a function of its pixel and sample index; only the draw count is stored
     const uint32_t pixPos = slot / (uint32_t)B.spp, sampleInPass = slot - pixPos * (uint32_t)B.spp;
-    Rng rng = rngInit(seed, (uint32_t)pixList[B.active ? B.active[pixPos] : (int32_t)pixPos], (uint32_t)sampleBase + sampleInPass, B.rng[slot]);
+    rng = rngInit(seed, (uint32_t)pixList[B.active ? B.active[pixPos] : (int32_t)pixPos], (uint32_t)sampleBase + sampleInPass, B.rng[slot]);
     float4 beta4 = B.beta[slot];
     V3 o = v3(o4.x, o4.y, o4.z), d = v3(d4.x, d4.y, d4.z);
     const bool onObject = prim >= 0 && prim < S.numPrims;
@@ -262,11 +281,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
       B.L[slot] = f4(L);
     } else {
       isHit = true;
-      V3 nd = normalized(d);
-      V3 point = t * nd + o;  // IntersectionInfo::point as the primitive computed it
-      V3 normal;
-      int32_t matIdx;
-      RGBA objColor;
+      nd = normalized(d);
+      point = t * nd + o;  // IntersectionInfo::point as the primitive computed it
       if (prim >= S.numPrims) {
         const DevPlane &pl = S.planes[prim - S.numPrims];
         normal = v3(pl.normal);
@@ -289,54 +305,89 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
         matIdx = od.material;
         objColor = rgba(od.color);
       }
-      V3 wo = -nd;
-      V3 outNormal = faceForward(wo, normal);
-      V3 biased = point + S.bias * outNormal;  // raytracer.cpp:228
-      RGBA beta = rgba(beta4);
-      // Inputs of the direct-light term L += beta * (getColor(biased) * sum_lights intensity), finished by k_shadow once
-      // visibility is known. Each light's unshadowed intensity (src/scene/Object.cpp:12-16, 27-34, 41-46) is evaluated
-      // here, in light order, so that environment lights draw their hemisphere direction before the BSDF draws.
+      outNormal = faceForward(-nd, normal);
+      biased = point + S.bias * outNormal;  // raytracer.cpp:228
+      beta = rgba(beta4);
+      // Inputs of the direct-light term L += beta * (getColor(biased) * sum_lights intensity), finished by k_direct once
+      // visibility is known.
       RGBA color = getColor(S, prim, biased, od);
       B.shPoint[slot] = make_float4(biased.x, biased.y, biased.z, 0);
       B.shColor[slot] = f4(color);
       B.shWeight[slot] = f4(beta);
-      for (int k = 0; k < S.numLights; ++k) {
-        const DevLight &l = S.lights[k];
-        RGBA lc = rgba(l.color[0], l.color[1], l.color[2], l.color[3]);
-        RGBA c;
-        if (l.type == RT_LIGHT_DISTANT) {
-          c = lc * clipDot(normal, v3(l.v));
-        } else if (l.type == RT_LIGHT_POINT) {
-          V3 lightDirection = v3(l.v) - biased;
-          float distance = magnitude(lightDirection);
-          float invDistance = 1.0f / (distance * distance);
-          c = lc * clipDot(normal, lightDirection) * invDistance;
-        } else {
-          V3 wi = sampleHemisphere(normal, rng);
-          B.envWi[(int64_t)l.envSlot * B.P + slot] = make_float4(wi.x, wi.y, wi.z, 0);
-          c = emittedLight(S, l, wi) * clipDot(normal, wi);
-        }
-        B.lightC[(int64_t)k * B.P + slot] = f4(c);
-      }
-      const DevMaterial &mat = S.materials[matIdx];
-      if (mat.type == RT_MAT_METAL) mulAssign(beta, objColor);  // raytracer.cpp:233-234
-      if (bounce + 1 < S.maxBounces) {
-        // The reference samples the BSDF on the last bounce too but never uses the result.
-        float pdf = 0.0f;
-        V3 wi;
-        float contribution = bsdfSample(mat, wo, wi, normal, rng, pdf);
-        if (!(pdf == 0 || contribution == 0)) {
-          continues = true;
-          mulAssign(beta, contribution * fabsf(dot(wi, normal)) / pdf);
-          bool exiting = dot(wi, outNormal) > 0;
-          V3 no = point + outNormal * (exiting ? S.bias : -S.bias);
-          B.rayO[slot] = make_float4(no.x, no.y, no.z, 0);
-          B.rayD[slot] = make_float4(wi.x, wi.y, wi.z, 0);
-        }
-      }
-      B.beta[slot] = f4(beta);
-      B.rng[slot] = rng.draws;
     }
+  }
+  // ------------------------------------------------------------------ part 2: the lights, in scene order
+  // Each light's unshadowed intensity (src/scene/Object.cpp:12-16, 27-34, 41-46) is evaluated here, so that environment
+  // lights draw their hemisphere direction before the BSDF draws, and so is everything about its visibility query that
+  // needs no traversal: a contribution of exactly (0, 0, 0) adds the same nothing whether the light is visible or not (the
+  // alpha of the sum is 1 from the start, src/scene/raytracer.cpp:199), and a plane that alone hides the light is found
+  // with the expressions the traversal engine uses for queries it prepares itself. The loop is reached by every lane of
+  // the wavefront: what was decided for 64 queue positions goes out as two 64-bit ballots.
+  for (int k = 0; k < S.numLights; ++k) {
+    int code = SHADOW_NONE;
+    if (isHit) {
+      const DevLight &l = S.lights[k];
+      RGBA lc = rgba(l.color[0], l.color[1], l.color[2], l.color[3]);
+      RGBA c;
+      V3 toLight;          // direction of the visibility query, as k_shadow forms it
+      float bulbDist = 0.0f;
+      if (l.type == RT_LIGHT_DISTANT) {
+        c = lc * clipDot(normal, v3(l.v));
+        toLight = v3(l.v);  // Object.cpp:7-10
+      } else if (l.type == RT_LIGHT_POINT) {
+        V3 lightDirection = v3(l.v) - biased;
+        float distance = magnitude(lightDirection);
+        float invDistance = 1.0f / (distance * distance);
+        c = lc * clipDot(normal, lightDirection) * invDistance;
+        toLight = lightDirection;  // Object.cpp:18-25
+        bulbDist = distance;
+      } else {
+        V3 wi = sampleHemisphere(normal, rng);
+        B.envWi[(int64_t)l.envSlot * B.P + slot] = make_float4(wi.x, wi.y, wi.z, 0);
+        c = emittedLight(S, l, wi) * clipDot(normal, wi);
+        toLight = wi;  // Object.cpp:36-39
+      }
+      float4 c4 = f4(c);
+      if (c4.x == 0.0f && c4.y == 0.0f && c4.z == 0.0f) {
+        code = SHADOW_ZERO;
+      } else {
+        code = SHADOW_TRACE;
+        if (S.numPlanes > 0) {
+          V3 qnd = normalized(toLight);
+          float tPlane; int32_t plane;
+          closestPlane(S, biased, qnd, tPlane, plane);
+          if (planeSettlesVisibility(l.type == RT_LIGHT_POINT, biased, qnd, bulbDist, tPlane, plane)) {
+            code = SHADOW_PLANE;
+            c4 = make_float4(0, 0, 0, 1);  // what a hidden light contributes
+          }
+        }
+      }
+      B.lightC[(int64_t)k * B.P + slot] = c4;
+    }
+    const unsigned long long lo = __ballot(code & 1), hi = __ballot(code & 2);
+    if (__lane_id() == 0)
+      B.shadowCode[(int64_t)k * B.rowsCap + (i >> 6)] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+  }
+  // ------------------------------------------------------------------ part 3: the next ray
+  if (isHit) {
+    const DevMaterial &mat = S.materials[matIdx];
+    if (mat.type == RT_MAT_METAL) mulAssign(beta, objColor);  // raytracer.cpp:233-234
+    if (bounce + 1 < S.maxBounces) {
+      // The reference samples the BSDF on the last bounce too but never uses the result.
+      float pdf = 0.0f;
+      V3 wi;
+      float contribution = bsdfSample(mat, -nd, wi, normal, rng, pdf);
+      if (!(pdf == 0 || contribution == 0)) {
+        continues = true;
+        mulAssign(beta, contribution * fabsf(dot(wi, normal)) / pdf);
+        bool exiting = dot(wi, outNormal) > 0;
+        V3 no = point + outNormal * (exiting ? S.bias : -S.bias);
+        B.rayO[slot] = make_float4(no.x, no.y, no.z, 0);
+        B.rayD[slot] = make_float4(wi.x, wi.y, wi.z, 0);
+      }
+    }
+    B.beta[slot] = f4(beta);
+    B.rng[slot] = rng.draws;
   }
   uint32_t qh, qn;
   queueSlots2(&B.counts->nHit, isHit, continues, qh, qn);
@@ -345,31 +396,37 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
 }
 
 // ---------------------------------------------------------------------------------------------------- k_shadow
-// One visibility query per (hit path, light), light-major so that a wavefront traces rays toward the same light.
-// A light that turns out to be hidden has its stored contribution replaced by RGBAColor(0, 0, 0, 1).
-// A light whose unshadowed contribution is already (0, 0, 0) — a surface facing away from a point or distant light —
-// adds the same nothing whether it is visible or not (the alpha of the sum is 1 from the start, src/scene/raytracer.cpp
-// :199), so its query is not traced. The reference traces it; such queries are counted apart.
+// One visibility query per (queue position, light), light-major so that a wavefront traces rays toward the same light.
+// k_shade has sorted them out already (ShadowCode): only SHADOW_TRACE queries are loaded and traced here, the others are
+// counted by kind. A light that turns out to be hidden has its stored contribution replaced by RGBAColor(0, 0, 0, 1).
+// The reference traces the zero-contribution queries too; they are reported apart.
 struct ShadowSource {
+  static constexpr bool kPlanesDone = true;  // k_shade has tested them
   const DevScene &S;
   const PathBuf &B;
-  uint32_t nHit;
-  uint32_t skippedPoint = 0, skippedAny = 0;
-  RT_DEV uint32_t total() const { return nHit * (uint32_t)S.numLights; }
+  const uint32_t *queue;  // the queue k_shade ran over
+  uint32_t nActive;       // its length
+  uint32_t zeroPoint = 0, zeroAny = 0, planePoint = 0, planeAny = 0, traced = 0;
+  RT_DEV uint32_t total() const { return nActive * (uint32_t)S.numLights; }
   RT_DEV uint32_t fetch(uint32_t idx, V3 &o, V3 &d, int &mode, float &bulbDist) {
-    uint32_t k = idx / nHit;
-    uint32_t slot = B.qHit[idx - k * nHit];
+    const uint32_t k = idx / nActive, pos = idx - k * nActive;
+    const uint32_t slot = queue[pos];  // read whether needed or not: one coalesced load that nothing has to wait for
+    const uint4 w = B.shadowCode[(int64_t)k * B.rowsCap + (pos >> 6)];
+    const uint32_t bit = pos & 31u;
+    const int code = (int)((((pos & 32u) ? w.y : w.x) >> bit) & 1u) | (int)(((((pos & 32u) ? w.w : w.z) >> bit) & 1u) << 1);
     const DevLight &l = S.lights[k];
-    float4 p4 = B.shPoint[slot];
-    float4 c4 = B.lightC[(int64_t)k * B.P + slot];
-    o = v3(p4.x, p4.y, p4.z);
-    mode = TRAV_ANY; bulbDist = 0.0f;
-    if (c4.x == 0.0f && c4.y == 0.0f && c4.z == 0.0f) {
-      if (l.type == RT_LIGHT_POINT) ++skippedPoint; else ++skippedAny;
-      d = v3(0, 0, 1);
-      mode = TRAV_SKIP;
+    mode = TRAV_SKIP; bulbDist = 0.0f;
+    o = v3(0, 0, 0); d = v3(0, 0, 1);
+    if (code != SHADOW_TRACE) {
+      const bool point = l.type == RT_LIGHT_POINT;
+      if (code == SHADOW_ZERO) { if (point) ++zeroPoint; else ++zeroAny; }
+      else if (code == SHADOW_PLANE) { if (point) ++planePoint; else ++planeAny; }
       return idx;
     }
+    ++traced;
+    float4 p4 = B.shPoint[slot];
+    o = v3(p4.x, p4.y, p4.z);
+    mode = TRAV_ANY;
     if (l.type == RT_LIGHT_DISTANT) {
       d = v3(l.v);  // Object.cpp:7-10
     } else if (l.type == RT_LIGHT_POINT) {
@@ -384,21 +441,22 @@ struct ShadowSource {
   }
   RT_DEV void store(uint32_t idx, HitRec, bool occluded, V3, V3) const {
     if (!occluded) return;
-    uint32_t k = idx / nHit;
-    uint32_t slot = B.qHit[idx - k * nHit];
+    const uint32_t k = idx / nActive;
+    const uint32_t slot = queue[idx - k * nActive];
     B.lightC[(int64_t)k * B.P + slot] = make_float4(0, 0, 0, 1);
   }
 };
 
 template <bool COUNT>
-__global__ RT_TRAV_ATTR void k_shadow(DevScene S, PathBuf B) {
+__global__ RT_TRAV_ATTR void k_shadow(DevScene S, PathBuf B, const uint32_t *queue) {
   __shared__ uint2 ldsStack[kStackLds * kBlock];
   __shared__ uint32_t ldsPool[(kBlock / 64) * kPoolFields * kPoolSlots];
   TravCounters tc{};
-  ShadowSource src{S, B, B.counts->nHit};
+  ShadowSource src{S, B, queue, B.counts->nActive};
   traverseQueue<ShadowSource, true, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[1].seg[0].next, ldsStack, ldsPool, tc);
+  if (COUNT) tc.planes += (src.traced + src.planePoint + src.planeAny) * (uint32_t)S.numPlanes;  // tested by k_shade
   flushCounters<COUNT>(B.counts, tc, 1);
-  uint32_t sp = src.skippedPoint, sa = src.skippedAny, pp = tc.planeAnsweredPoint, pa = tc.planeAnsweredAny;
+  uint32_t sp = src.zeroPoint, sa = src.zeroAny, pp = src.planePoint, pa = src.planeAny;
   for (int off = 32; off > 0; off >>= 1) {
     sp += __shfl_down(sp, off); sa += __shfl_down(sa, off); pp += __shfl_down(pp, off); pa += __shfl_down(pa, off);
   }
@@ -591,6 +649,7 @@ RT_DEV int32_t reportedId(const DevScene &S, int32_t prim) {
 }
 
 struct PrimarySource {
+  static constexpr bool kPlanesDone = false;
   const DevScene &S;
   int32_t x0, y0, w, h;
   int32_t *outPrim;
@@ -632,6 +691,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_primary(DevScene S, int32_t x0
 
 template <bool ANY>
 struct RaysSource {
+  static constexpr bool kPlanesDone = false;
   const DevScene &S;
   int64_t n;
   const float *origins, *directions;
@@ -1129,7 +1189,7 @@ int ensureRenderBuffers(RtScene *s, int64_t P, int64_t npix, int64_t fbPixels) {
     s->arena = nullptr; s->arenaP = 0; s->arenaBytes = 0;
     int64_t nEnv = std::max(1, s->numEnvLights);
     int64_t nLights = std::max(1, s->dev.numLights);
-    size_t bytes = (size_t)P * (sizeof(float4) * (7 + nEnv + nLights) + 4 * 6) + 4096;
+    size_t bytes = (size_t)P * (sizeof(float4) * (7 + nEnv + nLights) + 4 * 6) + (size_t)((P + 63) / 64) * sizeof(uint4) * nLights + 4096;
     HIP_TRY(hipMalloc(&s->arena, bytes));
     s->arenaBytes = bytes;
     s->arenaP = P;
@@ -1154,6 +1214,9 @@ int ensureRenderBuffers(RtScene *s, int64_t P, int64_t npix, int64_t fbPixels) {
   b.qA = reinterpret_cast<uint32_t *>(base); base += (size_t)cap * 4;
   b.qB = reinterpret_cast<uint32_t *>(base); base += (size_t)cap * 4;
   b.qHit = reinterpret_cast<uint32_t *>(base); base += (size_t)cap * 4;
+  base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(base) + 255) & ~(uintptr_t)255);
+  b.shadowCode = reinterpret_cast<uint4 *>(base);
+  b.rowsCap = (int32_t)((cap + 63) / 64);
   b.counts = s->counts;
   b.P = (int32_t)P;
   b.npix = (int32_t)npix;
@@ -1457,7 +1520,7 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
     HIP_TRY(hipMemGetInfo(&freeB, &totalB));
     const size_t avail = freeB + (s->arena ? s->arenaBytes : 0);
     const size_t budget = std::min<size_t>((size_t)64 << 30, avail / 2);
-    const size_t perPath = sizeof(float4) * (7 + std::max(1, s->numEnvLights) + std::max(1, s->dev.numLights)) + 4 * 6;
+    const size_t perPath = sizeof(float4) * (7 + std::max(1, s->numEnvLights) + std::max(1, s->dev.numLights)) + 4 * 6 + (size_t)std::max(1, s->dev.numLights);
     sppPass = (int)std::min<size_t>((size_t)S.numRays, std::max<size_t>(1, budget / (perPath * (size_t)std::max<int64_t>(1, npix))));
   }
   bool sppPassChosenHere = params->samplesPerPass <= 0;
@@ -1530,8 +1593,8 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
       if (S.numLights > 0) {
         if ((rc = beginEvent(s, CAT_SHADOW, timing))) return rc;
         unsigned gridShadow = persistentGrid(s, n * S.numLights);
-        if (count) k_shadow<true><<<gridShadow, kBlock, s->extraLds, st>>>(S, B);
-        else k_shadow<false><<<gridShadow, kBlock, s->extraLds, st>>>(S, B);
+        if (count) k_shadow<true><<<gridShadow, kBlock, s->extraLds, st>>>(S, B, qCur);
+        else k_shadow<false><<<gridShadow, kBlock, s->extraLds, st>>>(S, B, qCur);
         if ((rc = endEvent(s, timing))) return rc;
         ++launchesShadow;
       }
