@@ -178,8 +178,10 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DevScene S, PathBuf B, const 
       d = focusPoint - o;
     }
     B.rng[i] = rng.draws;
-    B.L[i] = make_float4(0, 0, 0, 0);
-    B.beta[i] = make_float4(1, 1, 1, 1);
+    // A live sample starts with L = (0, 0, 0, 0) and a path weight of (1, 1, 1, 1) (raytracer.cpp:209-210): the first bounce's
+    // kernels know that and neither read nor expect them, and they write L for every sample they see. Only a sample that
+    // never enters the queue (or a scene without a single bounce) needs its L written here.
+    if (!alive || S.maxBounces <= 0) B.L[i] = make_float4(0, 0, 0, 0);
     if (alive) {
       B.rayO[i] = make_float4(o.x, o.y, o.z, 0);
       B.rayD[i] = make_float4(d.x, d.y, d.z, 0);
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
     // the path's random stream is a function of its pixel and sample index; only the draw count is stored
     const uint32_t pixPos = slot / (uint32_t)B.spp, sampleInPass = slot - pixPos * (uint32_t)B.spp;
     rng = rngInit(seed, (uint32_t)pixList[B.active ? B.active[pixPos] : (int32_t)pixPos], (uint32_t)sampleBase + sampleInPass, B.rng[slot]);
-    float4 beta4 = B.beta[slot];
+    const float4 beta4 = bounce == 0 ? make_float4(1, 1, 1, 1) : B.beta[slot];  // bounce is uniform
     V3 o = v3(o4.x, o4.y, o4.z), d = v3(d4.x, d4.y, d4.z);
     const bool onObject = prim >= 0 && prim < S.numPrims;
     ObjectData od;
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
     }
     if (prim < 0) {
       // miss: add every light's emittedLight(direction) (raytracer.cpp:217-223); only environment lights emit
-      RGBA L = rgba(B.L[slot]);
+      RGBA L = bounce == 0 ? rgba(0, 0, 0, 0) : rgba(B.L[slot]);
       for (int k = 0; k < S.numLights; ++k) addAssign(L, emittedLight(S, S.lights[k], d));
       B.L[slot] = f4(L);
     } else {
@@ -386,8 +388,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
         B.rayD[slot] = make_float4(wi.x, wi.y, wi.z, 0);
       }
     }
-    B.beta[slot] = f4(beta);
-    B.rng[slot] = rng.draws;
+    if (bounce + 1 < S.maxBounces) {  // nothing reads them after the last bounce
+      B.beta[slot] = f4(beta);
+      B.rng[slot] = rng.draws;
+    }
   }
   uint32_t qh, qn;
   queueSlots2(&B.counts->nHit, isHit, continues, qh, qn);
@@ -469,13 +473,13 @@ __global__ RT_TRAV_ATTR void k_shadow(DevScene S, PathBuf B, const uint32_t *que
 }
 
 // L += beta * (getColor(point) * sum over lights, in scene order) — src/scene/raytracer.cpp:198-206, 231
-__global__ __launch_bounds__(kBlock) void k_direct(DevScene S, PathBuf B) {
+__global__ __launch_bounds__(kBlock) void k_direct(DevScene S, PathBuf B, int32_t bounce) {
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= B.counts->nHit) return;
   uint32_t slot = B.qHit[i];
   RGBA Lsum = rgba(0, 0, 0, 1);  // `RGBAColor L;`
   for (int k = 0; k < S.numLights; ++k) addAssign(Lsum, rgba(B.lightC[(int64_t)k * B.P + slot]));
-  RGBA L = rgba(B.L[slot]);
+  RGBA L = bounce == 0 ? rgba(0, 0, 0, 0) : rgba(B.L[slot]);  // a path's L is first written at its first bounce
   addAssign(L, rgba(B.shWeight[slot]) * (rgba(B.shColor[slot]) * Lsum));
   B.L[slot] = f4(L);
 }
@@ -1599,7 +1603,7 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
         ++launchesShadow;
       }
       if ((rc = beginEvent(s, CAT_DIRECT, timing))) return rc;
-      k_direct<<<grid, kBlock, 0, st>>>(S, B);
+      k_direct<<<grid, kBlock, 0, st>>>(S, B, bounce);
       if ((rc = endEvent(s, timing))) return rc;
       k_advance<<<1, 1, 0, st>>>(B, s->numPointLights, s->numAnyLights);
       std::swap(qCur, qNext);
