@@ -313,9 +313,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
       // Inputs of the direct-light term L += beta * (getColor(biased) * sum_lights intensity), finished by k_direct once
       // visibility is known.
       RGBA color = getColor(S, prim, biased, od);
-      B.shPoint[slot] = make_float4(biased.x, biased.y, biased.z, 0);
       B.shColor[slot] = f4(color);
-      B.shWeight[slot] = f4(beta);
+      if (bounce > 0) B.shWeight[slot] = f4(beta);  // (1, 1, 1, 1) at the first bounce: k_direct knows
     }
   }
   // ------------------------------------------------------------------ part 2: the lights, in scene order
@@ -325,6 +324,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
   // alpha of the sum is 1 from the start, src/scene/raytracer.cpp:199), and a plane that alone hides the light is found
   // with the expressions the traversal engine uses for queries it prepares itself. The loop is reached by every lane of
   // the wavefront: what was decided for 64 queue positions goes out as two 64-bit ballots.
+  bool anyTraced = false;
   for (int k = 0; k < S.numLights; ++k) {
     int code = SHADOW_NONE;
     if (isHit) {
@@ -345,7 +345,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
         bulbDist = distance;
       } else {
         V3 wi = sampleHemisphere(normal, rng);
-        B.envWi[(int64_t)l.envSlot * B.P + slot] = make_float4(wi.x, wi.y, wi.z, 0);
         c = emittedLight(S, l, wi) * clipDot(normal, wi);
         toLight = wi;  // Object.cpp:36-39
       }
@@ -365,11 +364,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
         }
       }
       B.lightC[(int64_t)k * B.P + slot] = c4;
+      if (code == SHADOW_TRACE) {  // what k_shadow reads of a query it traces
+        anyTraced = true;
+        if (l.type == RT_LIGHT_ENVIRONMENT) B.envWi[(int64_t)l.envSlot * B.P + slot] = make_float4(toLight.x, toLight.y, toLight.z, 0);
+      }
     }
     const unsigned long long lo = __ballot(code & 1), hi = __ballot(code & 2);
     if (__lane_id() == 0)
       B.shadowCode[(int64_t)k * B.rowsCap + (i >> 6)] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
   }
+  if (anyTraced) B.shPoint[slot] = make_float4(biased.x, biased.y, biased.z, 0);
   // ------------------------------------------------------------------ part 3: the next ray
   if (isHit) {
     const DevMaterial &mat = S.materials[matIdx];
@@ -480,7 +484,8 @@ __global__ __launch_bounds__(kBlock) void k_direct(DevScene S, PathBuf B, int32_
   RGBA Lsum = rgba(0, 0, 0, 1);  // `RGBAColor L;`
   for (int k = 0; k < S.numLights; ++k) addAssign(Lsum, rgba(B.lightC[(int64_t)k * B.P + slot]));
   RGBA L = bounce == 0 ? rgba(0, 0, 0, 0) : rgba(B.L[slot]);  // a path's L is first written at its first bounce
-  addAssign(L, rgba(B.shWeight[slot]) * (rgba(B.shColor[slot]) * Lsum));
+  const RGBA weight = bounce == 0 ? rgba(1, 1, 1, 1) : rgba(B.shWeight[slot]);
+  addAssign(L, weight * (rgba(B.shColor[slot]) * Lsum));
   B.L[slot] = f4(L);
 }
 
