@@ -459,6 +459,19 @@ def test_empty_and_degenerate_scenes(tmp_path):
     ref, _ = orc.render(seed=2)
     assert np.all(img[..., 3] == 1.0)
     assert psnr(img[..., :3], ref[..., :3]) >= PSNR_MIN_DB
+    # a path length of zero or one: no bounce ever writes a sample's radiance / every bounce is both first and last
+    o = hs.desc.contents.options
+    for bounces in (0, 1):
+        opt = capi.RtOptions(o.width, o.height, o.bias, o.exposure, bounces, o.numRays, o.fisheye, o.focus, o.lens)
+        dev.set_view(options=opt); orc.set_view(options=opt)
+        dev.render(seed=4)  # leaves the previous frame's state in the path buffers
+        img, _ = dev.render(seed=2)
+        ref, _ = orc.render(seed=2)
+        assert np.array_equal(img[..., 3], ref[..., 3])
+        if bounces == 0:
+            assert np.all(img == 0) and np.all(ref == 0)
+        else:
+            assert psnr(img[..., :3], ref[..., :3]) >= PSNR_MIN_DB
 
 
 def test_hip_library_rejects_what_it_cannot_do(scenes):
