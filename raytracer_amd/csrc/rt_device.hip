@@ -247,8 +247,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
   V3 nd = v3(0, 0, 0), point = nd, normal = nd, outNormal = nd, biased = nd;
   RGBA beta = rgba(0, 0, 0, 0), objColor = beta;
   int32_t matIdx = 0;
+  const uint32_t nActive = B.counts->nActive;
   // ------------------------------------------------------------------ part 1: the hit (or the miss)
-  if (i < B.counts->nActive) {
+  if (i < nActive) {
     slot = queue[i];
     // Loads that depend only on the path slot, then loads that depend only on the object, each group issued together:
     // the kernel is bound by the latency of these scattered reads, so they must not wait for one another.
@@ -370,7 +371,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
       }
     }
     const unsigned long long lo = __ballot(code & 1), hi = __ballot(code & 2);
-    if (__lane_id() == 0)
+    // lane 0 holds the wavefront's first queue position; a wavefront wholly beyond the queue has no entry (its row index
+    // may lie beyond this light's rows)
+    if (__lane_id() == 0 && i < nActive)
       B.shadowCode[(int64_t)k * B.rowsCap + (i >> 6)] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
   }
   if (anyTraced) B.shPoint[slot] = make_float4(biased.x, biased.y, biased.z, 0);

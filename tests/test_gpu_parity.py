@@ -226,6 +226,34 @@ def test_render_rng_free_scene_is_nearly_exact(scenes, golden):
     assert np.abs(dev.resolve_rgba8().astype(int) - golden("config1_rngfree")["render_rgba8"].astype(int)).max() <= 1
 
 
+@pytest.mark.parametrize("name", ["config1", "materials", "readme_small"])
+def test_path_counts_that_do_not_fill_a_block(name, scene_path):
+    """Frames whose number of paths is no multiple of the 256-thread block (and of the 64-lane wavefront), rendered as
+    the FIRST frame of a fresh device scene, so that every per-path buffer is exactly as long as this frame needs: the
+    last block's idle wavefronts must not write anything, least of all into the next light's part of a buffer. Scenes
+    with two and three lights; the frame must agree with the oracle's up to single diverged paths."""
+    hs = capi.HostScene.load(scene_path(name)).build()
+    o = hs.desc.contents.options
+    orc = oracle_scene(hs.desc)
+    try:
+        for w, h, spp in ((15, 36, 1), (37, 23, 3), (9, 7, 5), (65, 1, 1)):
+            opt = capi.RtOptions(w, h, o.bias, o.exposure, max(3, o.maxBounces), spp, o.fisheye, o.focus, o.lens)
+            dev = capi.device_scene(hs.desc)
+            try:
+                dev.set_view(options=opt); orc.set_view(options=opt)
+                img, st = dev.render(seed=11)
+                ref, ost = orc.render(seed=11)
+                assert (w * h * spp) % 64 != 0
+                assert np.array_equal(img[..., 3], ref[..., 3])
+                off = int((np.abs(img[..., :3] - ref[..., :3]).max(-1) > 1e-3).sum())
+                assert off <= max(2, w * h // 100), f"{name} {w}x{h}x{spp}: {off} pixels off"
+                assert st.raysShadow + st.raysSkipped == pytest.approx(ost.raysShadow, rel=0.02)
+            finally:
+                dev.close()
+    finally:
+        orc.close()
+
+
 def test_tile_partition_invariance(scenes):
     """1/2/4/8-way tile partitions of the same frame recombine into the un-partitioned image, bit for bit."""
     _, dev, _ = scenes("materials")
