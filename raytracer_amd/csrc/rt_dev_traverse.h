@@ -224,6 +224,10 @@ constexpr int kMaxTreeDepth = kMaxStack;
 //   uint32_t fetch(uint32_t idx, V3 &o, V3 &d, int &mode, float &bulbDist) load query idx, return a tag for store()
 //   void store(uint32_t tag, HitRec hit, bool occluded, V3 o, V3 nd)       deliver its result
 //   static constexpr bool kPlanesDone                                      the planes were tested before the query was queued
+//   static constexpr bool kFiltered                                        the queue is sparse and the source can tell cheaply where its
+//                                                                          queries are; it then also has
+//   int classify(uint32_t idx)                                             0 = nothing there, 1 = a query to fetch, other = see passedOver
+//   void passedOver(uint32_t idx, int kind)                                called once for every index classified > 1
 //
 // LDS the caller provides: ldsStack = K * BLOCK uint2 (stack columns), ldsPool = (BLOCK / 64) * kPoolFields * kPoolSlots dwords.
 
@@ -391,12 +395,12 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
     if (service && !exhausted && poolCount <= (uint32_t)kPoolLow) {
       const uint32_t want = (uint32_t)kPoolSlots - poolCount;  // <= 64
       const uint32_t avail = chunkEnd - chunkPos;
-      uint32_t idx = chunkPos + laneId;
-      bool fresh = false;  // lanes >= avail got an index from a new chunk
-      if (avail < want) {
-        // Queue indices come from a wave-local chunk [chunkPos, chunkEnd); one atomic on a shared counter buys
-        // kTicketChunk of them, so the counters (single addresses many wavefronts hit) see few operations.
-        uint32_t base = 0, end = 0;
+      // Queue indices come from a wave-local chunk [chunkPos, chunkEnd); one atomic on a shared counter buys
+      // kTicketChunk of them, so the counters (single addresses many wavefronts hit) see few operations.
+      const bool needChunk = Source::kFiltered ? avail == 0u : avail < want;
+      uint32_t idx = chunkPos + laneId;  // before the chunk changes: what is left of the old one is still handed out
+      uint32_t base = 0, end = 0;
+      if (needChunk) {
         while (segsLeft > 0) {
           const uint32_t segStart = (uint32_t)(((uint64_t)total * seg) / (uint32_t)kQueueSegments);
           const uint32_t segEnd = (uint32_t)(((uint64_t)total * (seg + 1)) / (uint32_t)kQueueSegments);
@@ -411,16 +415,36 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
           seg = (seg + 1) % (uint32_t)kQueueSegments;
           --segsLeft;
         }
-        if (segsLeft == 0) {
-          exhausted = true; chunkPos = chunkEnd = 0;
-        } else {
+        if (segsLeft == 0) { exhausted = true; chunkPos = chunkEnd = 0; }
+      }
+      const bool gotChunk = needChunk && !exhausted;
+      bool mine = false;  // this lane prepares query idx
+      if constexpr (Source::kFiltered) {
+        // The source knows cheaply which indices hold a query at all: a window of up to 64 indices is classified, and as
+        // many of them are used up as the pool has room for wanted ones. A sparse queue fills the pool in one round.
+        if (gotChunk) { chunkPos = base; chunkEnd = end; idx = chunkPos + laneId; }
+        const uint32_t window = min(64u, chunkEnd - chunkPos);  // 0 once the queue is exhausted
+        const int kind = laneId < window ? src.classify(idx) : 0;
+        const unsigned long long mWanted = __ballot(kind == 1);
+        uint32_t used = window;
+        if ((uint32_t)__popcll(mWanted) > want) {  // stop in front of the first wanted index that does not fit
+          const uint32_t rank = (uint32_t)__popcll(mWanted & ((1ull << laneId) - 1ull));
+          used = (uint32_t)__ffsll((long long)__ballot(kind == 1 && rank == want)) - 1u;
+        }
+        if (laneId < used && kind > 1) src.passedOver(idx, kind);
+        mine = laneId < used && kind == 1;
+        chunkPos += used;
+      } else {
+        bool fresh = false;  // lanes >= avail got an index from a new chunk
+        if (gotChunk) {
           fresh = true;
           if (laneId >= avail) idx = base + (laneId - avail);
           chunkPos = min(base + (want - avail), end);
           chunkEnd = end;
+        } else if (!needChunk) {
+          chunkPos += want;
         }
-      } else {
-        chunkPos += want;
+        mine = laneId < want && (laneId < avail || (fresh && idx < chunkEnd));
       }
       bool pooled = false;
       V3 qo = v3(0, 0, 0), qnd = qo, qinv = qo;
@@ -429,7 +453,7 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
       int qmode = TRAV_CLOSEST;
       bool qfinite = true;
       uint32_t qitem = 0;
-      if (laneId < want && (laneId < avail || (fresh && idx < chunkEnd))) {
+      if (mine) {
         V3 d;
         qitem = src.fetch(idx, qo, d, qmode, qbulb);
         if (!(RUNTIME_MODE && qmode == TRAV_SKIP)) {

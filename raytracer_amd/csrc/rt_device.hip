@@ -198,6 +198,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DevScene S, PathBuf B, const 
 // ---------------------------------------------------------------------------------------------------- k_extend
 struct ExtendSource {
   static constexpr bool kPlanesDone = false;
+  static constexpr bool kFiltered = false;
   const PathBuf &B;
   const uint32_t *queue;
   RT_DEV uint32_t total() const { return B.counts->nActive; }
@@ -408,36 +409,37 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
 
 // ---------------------------------------------------------------------------------------------------- k_shadow
 // One visibility query per (queue position, light), light-major so that a wavefront traces rays toward the same light.
-// k_shade has sorted them out already (ShadowCode): only SHADOW_TRACE queries are loaded and traced here, the others are
-// counted by kind. A light that turns out to be hidden has its stored contribution replaced by RGBAColor(0, 0, 0, 1).
+// k_shade has sorted them out already (ShadowCode): the traversal engine classifies 64 positions at a time, and only
+// SHADOW_TRACE queries are loaded and traced here, the others are counted by kind. A light that turns out to be hidden has its stored contribution replaced by RGBAColor(0, 0, 0, 1).
 // The reference traces the zero-contribution queries too; they are reported apart.
 struct ShadowSource {
   static constexpr bool kPlanesDone = true;  // k_shade has tested them
+  static constexpr bool kFiltered = true;    // and has left a code for every (queue position, light)
   const DevScene &S;
   const PathBuf &B;
   const uint32_t *queue;  // the queue k_shade ran over
   uint32_t nActive;       // its length
   uint32_t zeroPoint = 0, zeroAny = 0, planePoint = 0, planeAny = 0, traced = 0;
   RT_DEV uint32_t total() const { return nActive * (uint32_t)S.numLights; }
-  RT_DEV uint32_t fetch(uint32_t idx, V3 &o, V3 &d, int &mode, float &bulbDist) {
+  RT_DEV int classify(uint32_t idx) const {
     const uint32_t k = idx / nActive, pos = idx - k * nActive;
-    const uint32_t slot = queue[pos];  // read whether needed or not: one coalesced load that nothing has to wait for
     const uint4 w = B.shadowCode[(int64_t)k * B.rowsCap + (pos >> 6)];
     const uint32_t bit = pos & 31u;
-    const int code = (int)((((pos & 32u) ? w.y : w.x) >> bit) & 1u) | (int)(((((pos & 32u) ? w.w : w.z) >> bit) & 1u) << 1);
+    return (int)((((pos & 32u) ? w.y : w.x) >> bit) & 1u) | (int)(((((pos & 32u) ? w.w : w.z) >> bit) & 1u) << 1);  // a ShadowCode
+  }
+  RT_DEV void passedOver(uint32_t idx, int code) {
+    const bool point = S.lights[idx / nActive].type == RT_LIGHT_POINT;
+    if (code == SHADOW_ZERO) { if (point) ++zeroPoint; else ++zeroAny; }
+    else { if (point) ++planePoint; else ++planeAny; }
+  }
+  RT_DEV uint32_t fetch(uint32_t idx, V3 &o, V3 &d, int &mode, float &bulbDist) {
+    const uint32_t k = idx / nActive;
+    const uint32_t slot = queue[idx - k * nActive];
     const DevLight &l = S.lights[k];
-    mode = TRAV_SKIP; bulbDist = 0.0f;
-    o = v3(0, 0, 0); d = v3(0, 0, 1);
-    if (code != SHADOW_TRACE) {
-      const bool point = l.type == RT_LIGHT_POINT;
-      if (code == SHADOW_ZERO) { if (point) ++zeroPoint; else ++zeroAny; }
-      else if (code == SHADOW_PLANE) { if (point) ++planePoint; else ++planeAny; }
-      return idx;
-    }
     ++traced;
     float4 p4 = B.shPoint[slot];
     o = v3(p4.x, p4.y, p4.z);
-    mode = TRAV_ANY;
+    mode = TRAV_ANY; bulbDist = 0.0f;
     if (l.type == RT_LIGHT_DISTANT) {
       d = v3(l.v);  // Object.cpp:7-10
     } else if (l.type == RT_LIGHT_POINT) {
@@ -662,6 +664,7 @@ RT_DEV int32_t reportedId(const DevScene &S, int32_t prim) {
 
 struct PrimarySource {
   static constexpr bool kPlanesDone = false;
+  static constexpr bool kFiltered = false;
   const DevScene &S;
   int32_t x0, y0, w, h;
   int32_t *outPrim;
@@ -704,6 +707,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_primary(DevScene S, int32_t x0
 template <bool ANY>
 struct RaysSource {
   static constexpr bool kPlanesDone = false;
+  static constexpr bool kFiltered = false;
   const DevScene &S;
   int64_t n;
   const float *origins, *directions;
