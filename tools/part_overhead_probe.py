@@ -27,4 +27,5 @@ for n in (1, 2, 4, 8):
     wall, st = best
     rays = st.raysClosest + st.raysAny
     print(f"1/{n} of the frame: wall {wall:8.2f} ms, device {st.msTotal:8.2f} ms, host overhead {wall - st.msTotal:6.2f} ms, "
-          f"{rays / wall / 1e3:7.1f} Mrays/s per GPU, x{n} = {n * rays / wall / 1e3:8.1f}", flush=True)
+          f"{rays / wall / 1e3:7.1f} Mrays/s per GPU, x{n} = {n * rays / wall / 1e3:8.1f} | raygen {st.msRaygen:.2f} extend {st.msExtend:.2f} "
+          f"shade {st.msShade:.2f} shadow {st.msShadow:.2f} direct {st.msDirect:.2f} accumulate {st.msAccumulate:.2f} ms", flush=True)
