@@ -138,7 +138,10 @@ RT_DEV bool planeSettlesVisibility(bool pointLight, V3 o, V3 nd, float bulbDist,
 }
 
 #ifndef RT_CHUNK_MAX
-#define RT_CHUNK_MAX 256
+#define RT_CHUNK_MAX 128
+#endif
+#ifndef RT_CHUNK_MAX_FILTERED
+#define RT_CHUNK_MAX_FILTERED 256
 #endif
 #ifndef RT_CHUNK_DIV
 #define RT_CHUNK_DIV 16
@@ -153,7 +156,11 @@ RT_DEV bool planeSettlesVisibility(bool pointLight, V3 o, V3 nd, float bulbDist,
 #endif
 constexpr int kQueueSegments = RT_QUEUE_SEGMENTS;
 constexpr int kTicketStride = 32;  // dwords between the ticket counters of neighbouring segments
-constexpr uint32_t kTicketChunkMax = RT_CHUNK_MAX, kTicketChunkMin = 64, kChunksPerWave = RT_CHUNK_DIV;  // a prepare step takes up to 64 indices: a chunk must cover one
+// Indices per atomic: at most 128 of a dense queue, 256 of a sparse one (where under half of them hold a query). Smaller
+// chunks leave less for the last wavefronts of a launch (1/8 of the bench frame: k_extend 27.1 -> 25.9 ms; no difference on
+// the whole frame), still smaller ones make the ticket counters hot. A prepare step takes up to 64 indices: a chunk must
+// cover one.
+constexpr uint32_t kTicketChunkMax = RT_CHUNK_MAX, kTicketChunkMin = 64, kChunksPerWave = RT_CHUNK_DIV;
 
 enum { TRAV_CLOSEST = 0, TRAV_ANY = 1, TRAV_POINT_LIGHT = 2, TRAV_SKIP = 3 };
 
@@ -321,7 +328,8 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
   uint32_t chunkPos = 0, chunkEnd = 0;
   uint32_t seg = blockIdx.x % (uint32_t)kQueueSegments, segsLeft = (uint32_t)kQueueSegments;  // wave-uniform
   uint32_t poolHead = 0, poolCount = 0;  // wave-uniform ring of prepared queries
-  const uint32_t kTicketChunk = min(kTicketChunkMax, max(kTicketChunkMin, total / (gridDim.x * (BLOCK / 64) * kChunksPerWave)));
+  const uint32_t chunkMax = Source::kFiltered ? (uint32_t)RT_CHUNK_MAX_FILTERED : kTicketChunkMax;
+  const uint32_t kTicketChunk = min(chunkMax, max(kTicketChunkMin, total / (gridDim.x * (BLOCK / 64) * kChunksPerWave)));
 
   // object range [pi, pe) of a leaf reference (pe > 0 always: a leaf holds at least one object)
   auto setLeaf = [&](int32_t leaf) {
