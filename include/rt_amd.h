@@ -174,6 +174,8 @@ typedef struct RtStats {
   uint64_t innerExtend, primExtend;   /* the two counters above, split by kernel (only with collectCounters) */
   uint64_t innerShadow, primShadow;
   double msTotal;          /* render phase, device-side (HIP events on the library's stream) */
+  /* Device time by kernel family. A pass of fewer than 100 Mi paths traces a bounce's visibility queries and the next
+   * bounce's rays in ONE launch, timed under msShadow: msExtend then only holds the camera rays. */
   double msRaygen, msExtend, msShade, msShadow, msDirect, msAccumulate, msResolve;
   uint32_t launchesExtend, launchesShadow;
   uint32_t passes;

@@ -4,6 +4,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("RT_NO_FUSED_TRACE", "1")  # one kernel family per launch, so that the per-family columns mean what they say
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracer_amd import capi  # noqa: E402
 from tools import gen_scenes  # noqa: E402
