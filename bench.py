@@ -211,7 +211,13 @@ def main():
     ms_ext = sum(s.msExtend for s in stats); ms_sh = sum(s.msShadow for s in stats)
     rays_ext = sum(s.raysExtend for s in stats); rays_sh = sum(s.raysShadow for s in stats)
     launches_ext = sum(s.launchesExtend for s in stats); launches_sh = sum(s.launchesShadow for s in stats)
-    if ms_ext >= ms_sh:
+    fused = sum(s.launchesFused for s in stats)
+    if fused:
+        # short passes (a part of the frame per GPU): a bounce's visibility queries and the next bounce's rays share a launch
+        later = max(0, rays_ext - sum(s.cameraSamples for s in stats))
+        kname, kms, krays, klaunch = "k_shadow_then_extend", ms_sh, rays_sh + later, launches_sh
+        kb = (b_sh * rays_sh + b_ext * later) / max(1, krays)
+    elif ms_ext >= ms_sh:
         kname, kb, kms, krays, klaunch = "k_extend", b_ext, ms_ext, rays_ext, launches_ext
     else:
         kname, kb, kms, krays, klaunch = "k_shadow", b_sh, ms_sh, rays_sh, launches_sh
@@ -282,7 +288,8 @@ def main():
         "other_kernel": {"kernel": "k_shadow" if kname == "k_extend" else "k_extend",
                          "bytes_per_ray": round(b_sh if kname == "k_extend" else b_ext, 1),
                          "ms_total": round(ms_sh if kname == "k_extend" else ms_ext, 2),
-                         "rays": int(rays_sh if kname == "k_extend" else rays_ext)},
+                         "rays": int(rays_sh if kname == "k_extend" else (rays_ext - later if fused else rays_ext))},
+        "fused_launches": int(fused),
     }
 
     # ---- CPU baseline on this box's host cores, bounded sample: the compiled reference when its binary is here, else

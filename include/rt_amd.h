@@ -188,6 +188,9 @@ typedef struct RtStats {
    * raysShadow, which count traversed queries only */
   uint64_t raysSkipped;
   uint64_t raysPlaneAnswered;
+  /* launches (counted in launchesShadow) that traced a bounce's visibility queries AND the next bounce's rays; the time
+   * of those rays is then part of msShadow, their number still part of raysExtend */
+  uint32_t launchesFused;
 } RtStats;
 
 typedef struct RtScene RtScene;

@@ -91,7 +91,7 @@ class RtStats(C.Structure):
                 ("msResolve", C.c_double), ("launchesExtend", C.c_uint32), ("launchesShadow", C.c_uint32),
                 ("passes", C.c_uint32), ("laneUseInnerExtend", C.c_double), ("laneUsePrimExtend", C.c_double),
                 ("laneUseInnerShadow", C.c_double), ("laneUsePrimShadow", C.c_double), ("raysSkipped", C.c_uint64),
-                ("raysPlaneAnswered", C.c_uint64)]
+                ("raysPlaneAnswered", C.c_uint64), ("launchesFused", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

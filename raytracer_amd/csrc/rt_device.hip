@@ -1613,7 +1613,7 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
   if ((rc = beginEvent(s, CAT_TOTAL, timing))) return rc;
   size_t totalIdx = s->eventsUsed;
   if (timing) ++s->eventsUsed;  // the total pair stays open until the end
-  uint32_t passes = 0, launchesExtend = 0, launchesShadow = 0;
+  uint32_t passes = 0, launchesExtend = 0, launchesShadow = 0, launchesFused = 0;
   int64_t nPixPass = npix;            // pixels that take samples in the next pass (adaptive sampling shrinks it)
   int32_t *activeCur = nullptr, *activeNext = s->activeA;
   s->accValid = false;
@@ -1640,8 +1640,8 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
         if (count) k_extend<true><<<persistentGrid(s, n), kBlock, s->extraLds, st>>>(S, B, qCur, bounce);
         else k_extend<false><<<persistentGrid(s, n), kBlock, s->extraLds, st>>>(S, B, qCur, bounce);
         if ((rc = endEvent(s, timing))) return rc;
+        ++launchesExtend;
       }
-      ++launchesExtend;
       if ((rc = beginEvent(s, CAT_SHADE, timing))) return rc;
       k_shade<<<grid, kBlock, 0, st>>>(S, B, qCur, qNext, bounce, s->pixList, sBase, params->seed);
       if ((rc = endEvent(s, timing))) return rc;
@@ -1649,6 +1649,7 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
         if ((rc = beginEvent(s, CAT_SHADOW, timing))) return rc;
         unsigned gridShadow = persistentGrid(s, n * S.numLights);
         if (fuse && bounce + 1 < S.maxBounces) {
+          ++launchesFused;
           if (count) k_shadow_then_extend<true><<<gridShadow, kBlock, s->extraLds, st>>>(S, B, qCur, qNext, bounce);
           else k_shadow_then_extend<false><<<gridShadow, kBlock, s->extraLds, st>>>(S, B, qCur, qNext, bounce);
         } else if (count) k_shadow<true><<<gridShadow, kBlock, s->extraLds, st>>>(S, B, qCur);
@@ -1711,6 +1712,7 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
     stats->passes = passes;
     stats->launchesExtend = launchesExtend;
     stats->launchesShadow = launchesShadow;
+    stats->launchesFused = launchesFused;
     double ms[CAT_COUNT] = {0};
     for (size_t i = 0; i < s->eventsUsed; ++i) {
       float t = 0;
