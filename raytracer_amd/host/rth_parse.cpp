@@ -460,8 +460,9 @@ std::unique_ptr<Scene> readSdml(std::istream &in, std::string &error) {
 // ---------------------------------------------------------------------------------------------------- OBJ meshes
 // What the reference's loadOBJ accepts and produces (src/parser/parser.cpp:47-142), read differently: the file is
 // loaded once, scanned for `v` / `vn` lines and then for `f` lines (faces may name vertices that come later in the file,
-// as with the reference's two passes), numbers go through strtof / strtol (what std::stof / std::stoi call), and the
-// triangles (double-precision constants per triangle) are set up by all host threads.
+// as with the reference's two passes) — both scans by all host threads, on pieces of the text cut at line ends —
+// numbers go through strtof / strtol (what std::stof / std::stoi call), and the triangles (double-precision constants
+// per triangle) are set up by all host threads too.
 // Kept behaviours: only ' ' separates fields (a tab is part of a field); empty fields are dropped; extra fields are
 // ignored; a malformed or missing number is an error (the reference aborts on the uncaught exception); `a/b/c` and
 // `a//c` take normals, without transforming or normalising them, only when the FIRST corner has three fields;
@@ -537,82 +538,159 @@ bool loadOBJ(const Vec3 &center, float scale, const std::string &filename, Scene
     text.resize((size_t)infile.gcount());
   }
   const char *base = text.c_str(), *stop = base + text.size();
-  auto eachLine = [&](auto &&fn) {
+  // The text is cut at line ends into pieces that the host threads scan independently; per-piece results are joined in
+  // file order, and of the errors the pieces ran into the first one in file order is reported, so that the outcome is
+  // what one scan from top to bottom gives.
+  std::vector<const char *> cuts;
+  {
+    const size_t want = (size_t)std::max(1, hostThreads() * 4);
+    const size_t per = std::max<size_t>((size_t)1 << 16, text.size() / want + 1);
+    cuts.push_back(base);
     for (const char *b = base; b < stop;) {
-      const char *e = static_cast<const char *>(std::memchr(b, '\n', (size_t)(stop - b)));
-      if (!e) e = stop;
+      const char *q = b + std::min<size_t>(per, (size_t)(stop - b));
+      const char *e = q < stop ? static_cast<const char *>(std::memchr(q, '\n', (size_t)(stop - q))) : nullptr;
+      b = e ? e + 1 : stop;
+      cuts.push_back(b);
+    }
+  }
+  const int64_t numPieces = (int64_t)cuts.size() - 1;
+  struct Failure { int kind = 0; std::string what; };  // 1 out_of_range, 2 invalid_argument, 3 other
+  auto guarded = [](Failure &fail, auto &&body) {
+    try { body(); }
+    catch (const std::out_of_range &e) { fail.kind = 1; fail.what = e.what(); }
+    catch (const std::invalid_argument &e) { fail.kind = 2; fail.what = e.what(); }
+    catch (const std::exception &e) { fail.kind = 3; fail.what = e.what(); }
+  };
+  auto rethrowFirst = [](const std::vector<Failure> &fails) {
+    for (const Failure &f : fails) {
+      if (f.kind == 1) throw std::out_of_range(f.what);
+      if (f.kind == 2) throw std::invalid_argument(f.what);
+      if (f.kind == 3) throw std::runtime_error(f.what);
+    }
+  };
+  auto eachLineOf = [&](int64_t piece, auto &&fn) {
+    for (const char *b = cuts[(size_t)piece], *end = cuts[(size_t)piece + 1]; b < end;) {
+      const char *e = static_cast<const char *>(std::memchr(b, '\n', (size_t)(end - b)));
+      if (!e) e = end;
       fn(b, e);
       b = e + 1;
     }
   };
+  // pass 1: `v` and `vn` lines
+  struct VertexPiece { std::vector<Vec3> points, normals; Vec3 extMin{kInf, kInf, kInf}, extMax{-kInf, -kInf, -kInf}; };
+  std::vector<VertexPiece> vpieces((size_t)numPieces);
+  std::vector<Failure> fails((size_t)numPieces);
+  parallelItems(numPieces, [&](int64_t piece, int) {
+    VertexPiece &vp = vpieces[(size_t)piece];
+    std::vector<Field> f;
+    guarded(fails[(size_t)piece], [&]() {
+      eachLineOf(piece, [&](const char *b, const char *e) {
+        while (b < e && *b == ' ') ++b;
+        if (b == e || *b != 'v') return;  // only `v` and `vn` lines matter here
+        fieldsOf(b, e, f);
+        if (f.empty()) return;
+        if (isField(f[0], "v")) {
+          float x = fieldFloat(f, 1), y = fieldFloat(f, 2), z = fieldFloat(f, 3);
+          vp.extMin = Vec3(std::min(vp.extMin.x, x), std::min(vp.extMin.y, y), std::min(vp.extMin.z, z));
+          vp.extMax = Vec3(std::max(vp.extMax.x, x), std::max(vp.extMax.y, y), std::max(vp.extMax.z, z));
+          vp.points.emplace_back(x, y, z);
+        } else if (isField(f[0], "vn")) {
+          float x = fieldFloat(f, 1), y = fieldFloat(f, 2), z = fieldFloat(f, 3);
+          vp.normals.emplace_back(x, y, z);
+        }
+      });
+    });
+  });
+  rethrowFirst(fails);
   std::vector<Vec3> points, normals;
   Vec3 extMin(kInf, kInf, kInf), extMax(-kInf, -kInf, -kInf);
-  std::vector<Field> f;
-  eachLine([&](const char *b, const char *e) {
-    while (b < e && *b == ' ') ++b;
-    if (b == e || *b != 'v') return;  // only `v` and `vn` lines matter here
-    fieldsOf(b, e, f);
-    if (f.empty()) return;
-    if (isField(f[0], "v")) {
-      float x = fieldFloat(f, 1), y = fieldFloat(f, 2), z = fieldFloat(f, 3);
-      extMin = Vec3(std::min(extMin.x, x), std::min(extMin.y, y), std::min(extMin.z, z));
-      extMax = Vec3(std::max(extMax.x, x), std::max(extMax.y, y), std::max(extMax.z, z));
-      points.emplace_back(x, y, z);
-    } else if (isField(f[0], "vn")) {
-      float x = fieldFloat(f, 1), y = fieldFloat(f, 2), z = fieldFloat(f, 3);
-      normals.emplace_back(x, y, z);
+  {
+    size_t np = 0, nn = 0;
+    for (const VertexPiece &vp : vpieces) { np += vp.points.size(); nn += vp.normals.size(); }
+    points.reserve(np); normals.reserve(nn);
+    for (const VertexPiece &vp : vpieces) {
+      points.insert(points.end(), vp.points.begin(), vp.points.end());
+      normals.insert(normals.end(), vp.normals.begin(), vp.normals.end());
+      // std::min / std::max as above, piece after piece: a NaN coordinate is passed over either way
+      extMin = Vec3(std::min(extMin.x, vp.extMin.x), std::min(extMin.y, vp.extMin.y), std::min(extMin.z, vp.extMin.z));
+      extMax = Vec3(std::max(extMax.x, vp.extMax.x), std::max(extMax.y, vp.extMax.y), std::max(extMax.z, vp.extMax.z));
     }
-  });
+    vpieces.clear(); vpieces.shrink_to_fit();
+  }
   const int numPoints = (int)points.size();
+  // pass 2: `f` lines (a face may name vertices that come later in the file, hence after pass 1)
+  struct FacePiece { std::vector<Face> faces; std::vector<std::string> skipped; };
+  std::vector<FacePiece> fpieces((size_t)numPieces);
+  std::fill(fails.begin(), fails.end(), Failure{});
+  parallelItems(numPieces, [&](int64_t piece, int) {
+    FacePiece &fp = fpieces[(size_t)piece];
+    std::vector<Field> f;
+    guarded(fails[(size_t)piece], [&]() {
+      eachLineOf(piece, [&](const char *b, const char *e) {
+        while (b < e && *b == ' ') ++b;
+        if (b == e || *b != 'f') return;
+        fieldsOf(b, e, f);
+        if (f.empty() || !isField(f[0], "f")) return;
+        if (f.size() < 2) throw std::out_of_range("vector::_M_range_check");
+        int c1[3] = {-1, -1, -1}, c2[3], c3[3];
+        const int n1 = cornerOf(f[1], c1);
+        if (n1 < 1) throw std::out_of_range("vector::_M_range_check");
+        for (size_t idx = 2; idx + 1 < f.size(); ++idx) {  // triangle fan around the first corner
+          c2[0] = c2[1] = c2[2] = c3[0] = c3[1] = c3[2] = -1;
+          const int n2 = cornerOf(f[idx], c2), n3 = cornerOf(f[idx + 1], c3);
+          if (n2 < 1 || n3 < 1) throw std::out_of_range("vector::_M_range_check");
+          const int i = c1[0] - 1, j = c2[0] - 1, k = c3[0] - 1;
+          if (i >= numPoints || j >= numPoints || k >= numPoints) {
+            fp.skipped.push_back("Indices out of range: " + std::to_string(i) + ' ' + std::to_string(j) + ' ' + std::to_string(k));
+            continue;
+          }
+          if (i < 0 || j < 0 || k < 0) throw std::out_of_range("vector::_M_range_check");
+          Face face{{i, j, k}, {0, 0, 0}, n1 == 3};
+          if (face.withNormals) {
+            if (n2 < 3 || n3 < 3) throw std::out_of_range("vector::_M_range_check");
+            const int a = c1[2] - 1, bb = c2[2] - 1, c = c3[2] - 1, nn = (int)normals.size();
+            if (a < 0 || bb < 0 || c < 0 || a >= nn || bb >= nn || c >= nn) throw std::out_of_range("vector::_M_range_check");
+            face.n[0] = a; face.n[1] = bb; face.n[2] = c;
+          }
+          fp.faces.push_back(face);
+        }
+      });
+    });
+  });
+  rethrowFirst(fails);
   std::vector<Face> faces;
   std::vector<std::string> skipped;
-  eachLine([&](const char *b, const char *e) {
-    while (b < e && *b == ' ') ++b;
-    if (b == e || *b != 'f') return;
-    fieldsOf(b, e, f);
-    if (f.empty() || !isField(f[0], "f")) return;
-    if (f.size() < 2) throw std::out_of_range("vector::_M_range_check");
-    int c1[3] = {-1, -1, -1}, c2[3], c3[3];
-    const int n1 = cornerOf(f[1], c1);
-    if (n1 < 1) throw std::out_of_range("vector::_M_range_check");
-    for (size_t idx = 2; idx + 1 < f.size(); ++idx) {  // triangle fan around the first corner
-      c2[0] = c2[1] = c2[2] = c3[0] = c3[1] = c3[2] = -1;
-      const int n2 = cornerOf(f[idx], c2), n3 = cornerOf(f[idx + 1], c3);
-      if (n2 < 1 || n3 < 1) throw std::out_of_range("vector::_M_range_check");
-      const int i = c1[0] - 1, j = c2[0] - 1, k = c3[0] - 1;
-      if (i >= numPoints || j >= numPoints || k >= numPoints) {
-        skipped.push_back("Indices out of range: " + std::to_string(i) + ' ' + std::to_string(j) + ' ' + std::to_string(k));
-        continue;
-      }
-      if (i < 0 || j < 0 || k < 0) throw std::out_of_range("vector::_M_range_check");
-      Face face{{i, j, k}, {0, 0, 0}, n1 == 3};
-      if (face.withNormals) {
-        if (n2 < 3 || n3 < 3) throw std::out_of_range("vector::_M_range_check");
-        const int a = c1[2] - 1, bb = c2[2] - 1, c = c3[2] - 1, nn = (int)normals.size();
-        if (a < 0 || bb < 0 || c < 0 || a >= nn || bb >= nn || c >= nn) throw std::out_of_range("vector::_M_range_check");
-        face.n[0] = a; face.n[1] = bb; face.n[2] = c;
-      }
-      faces.push_back(face);
+  {
+    size_t nf = 0;
+    for (const FacePiece &fp : fpieces) nf += fp.faces.size();
+    faces.reserve(nf);
+    for (FacePiece &fp : fpieces) {
+      faces.insert(faces.end(), fp.faces.begin(), fp.faces.end());
+      for (std::string &m : fp.skipped) skipped.push_back(std::move(m));
     }
-  });
+    fpieces.clear(); fpieces.shrink_to_fit();
+  }
   for (std::string &m : skipped) scene.log.push_back(std::move(m));
   // parser.cpp:93-94
   const Vec3 shift = center - (extMax + extMin) / 2;
   const float scaleFactor = scale / maxDimension(extMax - extMin);
-  std::vector<Prim> tris(faces.size());
+  // Scene::addObject for every triangle, in file order (src/scene/raytracer.cpp:314-317): the records are built in place
+  // by all host threads, the running centroid sum — a float sum, so its order matters — is added up afterwards
+  const size_t first = scene.prims.size();
+  scene.prims.resize(first + faces.size());
   parallelChunks((int64_t)faces.size(), 1 << 12, [&](int64_t b, int64_t e, int) {
     for (int64_t t = b; t < e; ++t) {
       const Face &fc = faces[(size_t)t];
-      Prim p = makeTriangle(scaleFactor * points[(size_t)fc.v[0]] + shift, scaleFactor * points[(size_t)fc.v[1]] + shift,
-                            scaleFactor * points[(size_t)fc.v[2]] + shift, color, material);
+      Prim &p = scene.prims[first + (size_t)t];
+      p = makeTriangle(scaleFactor * points[(size_t)fc.v[0]] + shift, scaleFactor * points[(size_t)fc.v[1]] + shift,
+                       scaleFactor * points[(size_t)fc.v[2]] + shift, color, material);
       if (fc.withNormals) {
         p.n1 = normals[(size_t)fc.n[0]]; p.n2 = normals[(size_t)fc.n[1]]; p.n3 = normals[(size_t)fc.n[2]];
       }
-      tris[(size_t)t] = p;
+      p.origIndex = (int)(first + (size_t)t);
     }
   });
-  scene.prims.reserve(scene.prims.size() + tris.size());
-  for (const Prim &p : tris) scene.addPrim(p);  // in file order: the centroid sum is a float sum
+  for (size_t t = first; t < scene.prims.size(); ++t) scene.centroidSum = scene.centroidSum + scene.prims[t].centroid;
   scene.log.push_back("Scanned " + std::to_string(points.size()) + " points and " + std::to_string(faces.size()) + " objects");
   return true;
 }

@@ -126,6 +126,35 @@ def test_png_pixels_roundtrip(tmp_path):
     assert np.array_equal(capi.to_srgb8(lin), rgba8)
 
 
+def test_png_written_in_parallel_pieces_is_one_valid_stream(tmp_path):
+    """The encoder deflates the image in independent 512 KiB pieces on the host threads and joins them into one zlib
+    stream: an image of several pieces (and sizes around the piece boundary) must decode — with Python's zlib, and
+    with the library's own decoder — to the bytes that went in, with every chunk CRC right."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(5)
+    for w, h in ((700, 600), (1, 1), (363, 361), (131071, 1), (512, 256)):
+        rgba8 = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+        rgba8[:, : w // 2] = 9  # one half compresses, the other does not
+        p = str(tmp_path / f"p{w}x{h}.png")
+        capi.png_write_rgba8(p, rgba8)
+        data = open(p, "rb").read()
+        assert data[:8] == b"\x89PNG\r\n\x1a\n"
+        pos, idat, kinds = 8, b"", []
+        while pos < len(data):
+            n, = struct.unpack(">I", data[pos:pos + 4])
+            kind, body = data[pos + 4:pos + 8], data[pos + 8:pos + 8 + n]
+            assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(kind + body) & 0xFFFFFFFF
+            kinds.append(kind)
+            if kind == b"IDAT":
+                idat += body
+            pos += 12 + n
+        assert kinds[0] == b"IHDR" and kinds[-1] == b"IEND"
+        rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w * 4 + 1)
+        assert (rows[:, 0] == 0).all() and np.array_equal(rows[:, 1:].reshape(h, w, 4), rgba8)
+        assert np.array_equal(capi.png_read_rgba8(p), rgba8)
+
+
 def _png_with_ihdr(path, width, height, depth, ctype, compression=0, flt=0, interlace=0):
     import struct
     import zlib
@@ -201,6 +230,48 @@ def test_obj_loader_rejects_what_the_reference_aborts_on(tmp_path, body, needle)
         f"  <Wavefront path=\"{tmp_path / 'm.obj'}\" options={{center: (0, 0, -3); scale: 1}}>\n  </Wavefront>\n</Scene>\n")
     with pytest.raises(RuntimeError, match=needle):
         capi.HostScene.load(str(tmp_path / "s.sdml"))
+
+
+def test_obj_loader_on_a_file_of_many_pieces_reports_what_a_top_to_bottom_scan_would(tmp_path):
+    """The OBJ text is scanned in pieces by the host threads. A file long enough for several pieces gives the same mesh
+    with any thread count, and with errors in several pieces the one a sequential two-pass reader meets first is
+    reported: any `v` error before any `f` error, and of two errors in the same pass the one higher up in the file."""
+    n = 40000  # ~1.5 MB of text: more than twenty pieces of 64 KiB
+    rng = np.random.default_rng(2)
+    pts = rng.normal(size=(n, 3))
+    lines = [f"v {x:.6f} {y:.6f} {z:.6f}" for x, y, z in pts]
+    faces = [f"f {i + 1} {(i + 7) % n + 1} {(i + 13) % n + 1}" for i in range(n)]
+    sdml = ("<Scene options={width: 8; height: 8; filename: o.png}>\n  <Camera options={}/>\n"
+            f"  <Wavefront path=\"{tmp_path / 'm.obj'}\" options={{center: (0, 0, -3); scale: 1}}>\n  </Wavefront>\n</Scene>\n")
+    (tmp_path / "s.sdml").write_text(sdml)
+
+    def load(vlines, flines, threads):
+        (tmp_path / "m.obj").write_text("\n".join(vlines + flines) + "\n")
+        capi.set_host_threads(threads)
+        try:
+            return capi.HostScene.load(str(tmp_path / "s.sdml"))
+        finally:
+            capi.set_host_threads(0)
+
+    hashes = []
+    for threads in (1, 3, 16):
+        hs = load(lines, faces, threads).build()
+        d = hs.desc.contents
+        assert d.numPrims == n
+        hashes.append((sha1(np.ctypeslib.as_array(d.primHit, shape=(d.numPrims * 12,)).copy()), sha1(hs.nodes())))
+    assert hashes[0] == hashes[1] == hashes[2]
+    # a face error near the top, a vertex error near the bottom: the vertex scan comes first ("stof", not a range check)
+    bad_v = list(lines); bad_v[n - 5] = "v 1 x 0"
+    bad_f = list(faces); bad_f[3] = "f 0 1 2"
+    with pytest.raises(RuntimeError, match="stof"):
+        load(bad_v, bad_f, 16)
+    # two vertex errors: a missing coordinate high up (range check), not a number far below (stof)
+    bad_v = list(lines); bad_v[10] = "v 1 2"; bad_v[n - 5] = "v 1 x 0"
+    with pytest.raises(RuntimeError, match="range_check"):
+        load(bad_v, faces, 16)
+    bad_v = list(lines); bad_v[10] = "v 1 x 0"; bad_v[n - 5] = "v 1 2"
+    with pytest.raises(RuntimeError, match="stof"):
+        load(bad_v, faces, 16)
 
 
 def test_host_thread_count_never_changes_the_result(scene_path):
