@@ -3,13 +3,19 @@
 // empty side, objects regrouped with std::partition), because the leaf order it produces decides which object wins a
 // tie in t (BVH.cpp:308-313) and therefore the hit ids. The SCHEDULE is this library's own: the tree is split top-down
 // with all host threads binning each large node together until the pieces are small, then the pieces are built
-// concurrently, one thread each. Bin boxes and counts are min / max / integer sums, so neither the thread count nor the
+// concurrently from a shared queue of subtrees. Bin boxes and counts are min / max / integer sums, so neither the thread count nor the
 // order of the pieces changes a single bit of the result; node numbers are assigned afterwards by a pre-order walk
 // (left child = index + 1, BVH.cpp:411-428).
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
 #include <atomic>
+#include <condition_variable>
 #include <limits>
+#include <mutex>
 #include <numeric>
+#include <thread>
 
 #include "rth_scene.h"
 #include "rth_threads.h"
@@ -20,6 +26,7 @@ namespace {
 constexpr int kBins = 16;          // N_BUCKETS, BVH.cpp:9
 constexpr int kLeafObjects = 4;    // MIN_LEAF_SIZE, BVH.cpp:11
 constexpr int kSharedNode = 1 << 16;  // nodes with at least this many objects are binned by all threads together
+constexpr int kTaskNode = 1 << 12;    // below that: a subtree with fewer objects than this is built by one thread in one go
 constexpr float kInf = std::numeric_limits<float>::infinity();
 
 struct Bounds {
@@ -56,7 +63,12 @@ struct Split { int axis = -1; float position = 0, cost = kInf; };
 
 class TreeBuilder {
  public:
-  explicit TreeBuilder(const std::vector<Prim> &p) : prims_(p.size()), order_(p.size()), nodes_(2 * p.size() + 1) {
+  explicit TreeBuilder(const std::vector<Prim> &p)
+      : prims_(p.size()), order_(p.size()), nodeStore_(std::malloc((2 * p.size() + 1) * sizeof(TreeNode))),
+        nodes_(static_cast<TreeNode *>(nodeStore_.get())) {
+    // 2 n + 1 nodes at most, 40 bytes each: constructed one by one as the tree grows, not all of them up front
+    if (!nodes_) throw std::bad_alloc();
+    new (&nodes_[0]) TreeNode();
     // the build only looks at boxes and centroids: 36 bytes per object instead of the whole record
     parallelChunks((int64_t)p.size(), 1 << 14, [&](int64_t b, int64_t e, int) {
       for (int64_t i = b; i < e; ++i) {
@@ -79,8 +91,33 @@ class TreeBuilder {
       if (nodes_[n].count < kSharedNode) { pieces.push_back(n); continue; }
       if (splitNode(n, true)) { open.push_back(nodes_[n].right); open.push_back(nodes_[n].left); }
     }
-    // the rest: independent subtrees, one thread each
-    parallelItems((int64_t)pieces.size(), [&](int64_t i, int) { buildSubtree(pieces[(size_t)i]); });
+    // The rest: independent subtrees. A worker that takes a large one splits its root and hands the two halves back, so
+    // the work spreads over the threads however unevenly the top of the tree came out; small ones are built whole.
+    std::mutex m;
+    std::condition_variable cv;
+    int busy = 0;
+    auto worker = [&]() {
+      std::unique_lock<std::mutex> lock(m);
+      while (true) {
+        cv.wait(lock, [&] { return !pieces.empty() || busy == 0; });
+        if (pieces.empty()) { cv.notify_all(); return; }  // nothing queued and nobody who could queue more
+        const int n = pieces.back(); pieces.pop_back();
+        ++busy;
+        lock.unlock();
+        bool split = false;
+        if (nodes_[(size_t)n].count >= kTaskNode) split = splitNode(n, false);
+        else buildSubtree(n);
+        lock.lock();
+        if (split) { pieces.push_back(nodes_[(size_t)n].right); pieces.push_back(nodes_[(size_t)n].left); }
+        --busy;
+        cv.notify_all();
+      }
+    };
+    const int workers = std::max(1, std::min(hostThreads(), (int)prims_.size() / kTaskNode + 1));
+    if (workers <= 1) { worker(); return; }
+    std::vector<std::thread> pool;
+    for (int w = 0; w < workers; ++w) pool.emplace_back(worker);
+    for (auto &t : pool) t.join();
   }
 
   // pre-order numbering; returns the node count
@@ -110,7 +147,9 @@ class TreeBuilder {
   struct BuildPrim { Vec3 aabbMin, aabbMax, centroid; };
   std::vector<BuildPrim> prims_;
   std::vector<int> order_;  // order_[i] = index into prims_ of the object at BVH position i
-  std::vector<TreeNode> nodes_;
+  struct FreeDeleter { void operator()(void *p) const { std::free(p); } };
+  std::unique_ptr<void, FreeDeleter> nodeStore_;
+  TreeNode *nodes_;
   std::atomic<int> used_{0};
 
   const BuildPrim &at(int i) const { return prims_[(size_t)order_[(size_t)i]]; }
@@ -210,18 +249,57 @@ class TreeBuilder {
     if (s.cost >= node.box.area() * node.count) return false;
     // The reference regroups with libstdc++'s std::partition on random-access iterators; it is not stable, and the
     // order it leaves is part of the contract, so the same algorithm object is used.
-    auto lo = order_.begin() + node.first, hi = lo + node.count;
     const int axis = s.axis; const float pos = s.position;
-    auto mid = std::partition(lo, hi, [&](int idx) { return prims_[(size_t)idx].centroid[axis] < pos; });
-    int nLeft = (int)(mid - lo);
+    const int nLeft = shared ? partitionShared(node.first, node.count, axis, pos)
+                             : (int)(std::partition(order_.begin() + node.first, order_.begin() + node.first + node.count,
+                                                    [&](int idx) { return prims_[(size_t)idx].centroid[axis] < pos; }) -
+                                     (order_.begin() + node.first));
     if (nLeft == 0 || nLeft == node.count) return false;
     int l = used_.fetch_add(2), r = l + 1;
+    new (&nodes_[l]) TreeNode();
+    new (&nodes_[r]) TreeNode();
     nodes_[(size_t)l].first = node.first; nodes_[(size_t)l].count = nLeft;
     nodes_[(size_t)r].first = node.first + nLeft; nodes_[(size_t)r].count = node.count - nLeft;
     nodes_[(size_t)l].box = boundsOf(nodes_[(size_t)l].first, nodes_[(size_t)l].count, shared);
     nodes_[(size_t)r].box = boundsOf(nodes_[(size_t)r].first, nodes_[(size_t)r].count, shared);
     node.left = l; node.right = r; node.count = 0;
     return true;
+  }
+
+  // std::partition of order_[first, first + count) by "centroid[axis] < pos", by all threads, with the result of
+  // libstdc++'s algorithm for random-access iterators: that one walks inward from both ends and swaps the i-th element
+  // from the left that fails the test with the i-th element from the right that passes it, until the two walks meet —
+  // at first + (number of passing elements). So: the elements left of that point that fail, in ascending order, change
+  // places with the elements right of it that pass, in descending order. Returns the number of passing elements.
+  int partitionShared(int first, int count, int axis, float pos) {
+    const int threads = hostThreads();
+    std::vector<uint8_t> pass((size_t)count);
+    std::vector<int64_t> passing((size_t)threads, 0);
+    parallelChunks(count, 1 << 14, [&](int64_t b, int64_t e, int chunk) {
+      int64_t n = 0;
+      for (int64_t i = b; i < e; ++i) {
+        const bool p = at(first + (int)i).centroid[axis] < pos;
+        pass[(size_t)i] = p; n += p;
+      }
+      passing[(size_t)chunk] = n;
+    });
+    int64_t mid = 0;
+    for (int64_t n : passing) mid += n;
+    // positions (relative to first) that have to move, per chunk and in ascending order
+    std::vector<std::vector<int>> failLeft((size_t)threads), passRight((size_t)threads);
+    parallelChunks(count, 1 << 14, [&](int64_t b, int64_t e, int chunk) {
+      for (int64_t i = b; i < std::min(e, mid); ++i) if (!pass[(size_t)i]) failLeft[(size_t)chunk].push_back((int)i);
+      for (int64_t i = std::max(b, mid); i < e; ++i) if (pass[(size_t)i]) passRight[(size_t)chunk].push_back((int)i);
+    });
+    std::vector<int> fromLeft, fromRight;
+    for (const auto &v : failLeft) fromLeft.insert(fromLeft.end(), v.begin(), v.end());
+    for (const auto &v : passRight) fromRight.insert(fromRight.end(), v.begin(), v.end());
+    const int64_t swaps = (int64_t)fromLeft.size();  // == fromRight.size(): as many fail on the left as pass on the right
+    parallelChunks(swaps, 1 << 12, [&](int64_t b, int64_t e, int) {
+      for (int64_t i = b; i < e; ++i)
+        std::swap(order_[(size_t)first + (size_t)fromLeft[(size_t)i]], order_[(size_t)first + (size_t)fromRight[(size_t)(swaps - 1 - i)]]);
+    });
+    return (int)mid;
   }
 
   void buildSubtree(int root) {
@@ -246,12 +324,20 @@ void buildBVH(Scene &scene) {
   tb.build();
   int numNodes = tb.flatten(scene.nodes);
   // Scene::objects end up in leaf order (BVH.cpp:258 reorders them in place)
-  std::vector<Prim> reordered(scene.prims.size());
+  // through a buffer nobody has initialised (200 bytes per object: filling a fresh vector first would be the longest
+  // single-threaded step of the build), gathered and copied back by all threads
+  static_assert(std::is_trivially_copyable<Prim>::value, "Prim is moved with memcpy");
+  struct FreeDeleter { void operator()(void *p) const { std::free(p); } };
+  std::unique_ptr<void, FreeDeleter> raw(std::malloc(scene.prims.size() * sizeof(Prim)));
+  if (!raw) throw std::bad_alloc();
+  char *buffer = static_cast<char *>(raw.get());
   const std::vector<int> &order = tb.order();
   parallelChunks((int64_t)order.size(), 1 << 14, [&](int64_t b, int64_t e, int) {
-    for (int64_t i = b; i < e; ++i) reordered[(size_t)i] = scene.prims[(size_t)order[(size_t)i]];
+    for (int64_t i = b; i < e; ++i) std::memcpy(buffer + (size_t)i * sizeof(Prim), &scene.prims[(size_t)order[(size_t)i]], sizeof(Prim));
   });
-  scene.prims.swap(reordered);
+  parallelChunks((int64_t)order.size(), 1 << 14, [&](int64_t b, int64_t e, int) {
+    std::memcpy(static_cast<void *>(&scene.prims[(size_t)b]), buffer + (size_t)b * sizeof(Prim), (size_t)(e - b) * sizeof(Prim));
+  });
   scene.log.push_back("BVH created with " + std::to_string(numNodes) + " nodes on " +
                       std::to_string(scene.prims.size()) + " objects.");
 }

@@ -105,7 +105,8 @@ bool flatten(const Scene &scene, FlatScene &out, std::string &error, bool requir
   bool anyTexturedTriangle = false;
   for (const Prim &p : scene.prims) anyTexturedTriangle |= (p.kind == RT_PRIM_TRIANGLE && p.texture >= 0);
   if (anyTexturedTriangle) out.primTexCoords.assign(n * 9, 0.0f); else out.primTexCoords.clear();
-  for (size_t i = 0; i < n; ++i) {
+  parallelChunks((int64_t)n, 1 << 14, [&](int64_t begin, int64_t end, int) {
+   for (size_t i = (size_t)begin; i < (size_t)end; ++i) {
     const Prim &p = scene.prims[i];
     out.primKind[i] = p.kind; out.primMaterial[i] = p.material; out.primTexture[i] = p.texture;
     out.primOrigIndex[i] = p.origIndex;
@@ -122,7 +123,8 @@ bool flatten(const Scene &scene, FlatScene &out, std::string &error, bool requir
     }
     out.primColor[i * 4 + 0] = p.color.r; out.primColor[i * 4 + 1] = p.color.g;
     out.primColor[i * 4 + 2] = p.color.b; out.primColor[i * 4 + 3] = p.color.a;
-  }
+   }
+  });
   out.planes.clear();
   for (const Plane &p : scene.planes) {
     RtPlane q{};
