@@ -48,6 +48,8 @@ double now() {
 
 int usage(const char *argv0, int code) {
   std::fprintf(stderr, "usage: %s [-t numThreads] filepath\n", argv0);
+  std::fprintf(stderr, "       further options: --gpus N [--share-gpus] --stats --seed S --tile WxH --spp-pass K --device-bvh\n"
+                       "                        --adaptive THRESHOLD [--adaptive-batch B] --dump-hits FILE\n");
   return code;
 }
 
