@@ -169,6 +169,41 @@ def test_config5_full_size_10M_triangles_4k_64spp():
         dev.close(); orc.close()
 
 
+@pytest.mark.parametrize("name", ["spiral", "tenthousand"])
+def test_scenes_the_reference_ships(name, golden):
+    """example_scenes/scene_files/spiral.txt and tenthousand.txt of the reference (carried as arrays, see
+    tests/desc_fixture.py): primary hits at the scenes' own 800 x 800 equal the compiled reference's, ids and bits of t;
+    incoherent closest / any queries equal the oracle's; the frame at the scene's own settings (tenthousand: 40 samples,
+    16 bounces, depth of field) is within the PSNR bar of the oracle's at matched streams, alpha exact."""
+    from raytracer_amd import multi_gpu
+    from tests.desc_fixture import DescFromArrays
+    g = golden("bundled_" + name)
+    w, h = int(g["width"]), int(g["height"])
+    full = DescFromArrays(g)
+    dev, orc = capi.device_scene(full.desc), oracle_scene(full.desc, threads=16)
+    try:
+        ids, t = dev.trace_primary()
+        assert sha1(ids) == str(g["hit_ids_sha1"]) and sha1(t.view(np.uint32)) == str(g["hit_tbits_sha1"])
+        r0, r1 = (int(x) for x in g["band_rows"])
+        assert np.array_equal(ids.reshape(h, w)[r0:r1].ravel(), g["band_ids"])
+        o, d = _random_rays(50_000, 31)
+        for a, b in zip(dev.trace_closest(o, d), orc.trace_closest(o, d)):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert np.array_equal(dev.trace_any(o, d), orc.trace_any(o, d))
+        # a 16th of the frame's tiles at the scene's full sample count and path length against the oracle
+        own = multi_gpu.tile_owner(w, h, (32, 32), 16) == 3
+        part, st = dev.render(seed=7, part_index=3, part_count=16, tile=(32, 32))
+        ref, ost = orc.render(seed=7, part_index=3, part_count=16, tile=(32, 32))
+        assert st.cameraSamples == ost.cameraSamples
+        assert np.array_equal(part[..., 3], ref[..., 3])
+        assert psnr(part[own][:, :3], ref[own][:, :3]) >= PSNR_MIN_DB
+        whole, stw = dev.render(seed=7)
+        assert np.isfinite(whole).all() and whole.min() >= 0.0 and whole.max() <= 1.0
+        assert np.array_equal(whole[own].view(np.uint32), part[own].view(np.uint32))
+    finally:
+        dev.close(); orc.close()
+
+
 def _random_rays(n, seed, spread=4.0):
     rng = np.random.default_rng(seed)
     o = (rng.normal(size=(n, 3)) * np.array([spread, spread * 0.6, spread]) + np.array([0, 0.3, -3])).astype(np.float32)

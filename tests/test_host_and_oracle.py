@@ -77,6 +77,35 @@ def test_oracle_render_replays_reference_t1(name, scene_path, golden):
     assert st.raysClosest > 0
 
 
+@pytest.mark.parametrize("name", ["spiral", "tenthousand"])
+def test_oracle_on_the_scenes_the_reference_ships(name, golden):
+    """example_scenes/scene_files/spiral.txt (5000 spheres, two suns) and tenthousand.txt (10 000 spheres, depth of field,
+    16 bounces) of the reference, carried as arrays (tests/desc_fixture.py): primary hits at the scenes' own 800 x 800
+    equal the compiled reference's (ids and bits of t, by hash and on a band of rows), and the -t1 frame at a reduced size
+    equals the reference's float frame and PNG bytes."""
+    from tests.desc_fixture import DescFromArrays
+    g = golden("bundled_" + name)
+    w, h = int(g["width"]), int(g["height"])
+    full = DescFromArrays(g)
+    osc = oracle_scene(full.desc)
+    ids, t = osc.trace_primary()
+    assert sha1(ids) == str(g["hit_ids_sha1"]) and sha1(t.view(np.uint32)) == str(g["hit_tbits_sha1"])
+    r0, r1 = (int(x) for x in g["band_rows"])
+    assert np.array_equal(ids.reshape(h, w)[r0:r1].ravel(), g["band_ids"])
+    assert np.array_equal(t.view(np.uint32).reshape(h, w)[r0:r1].ravel(), g["band_tbits"])
+    assert int((ids >= 0).sum()) == int(g["num_hits"])
+    osc.close()
+    side = int(g["small_side"])
+    small = DescFromArrays(g, side, side)
+    osc = oracle_scene(small.desc)
+    ids, t = osc.trace_primary()
+    assert np.array_equal(ids.ravel(), g["small_hit_ids"]) and np.array_equal(t.view(np.uint32).ravel(), g["small_hit_tbits"])
+    img, _ = osc.render(rng_mode=capi.RT_RNG_REF_MT19937)
+    assert np.array_equal(img.view(np.uint32), g["small_render_f32"].view(np.uint32))
+    assert np.array_equal(osc.resolve_rgba8(), g["small_render_rgba8"])
+    osc.close()
+
+
 def test_oracle_counter_mode_partition_invariant(scene_path):
     """Counter RNG: the image does not depend on the tile partition or the thread count."""
     hs = capi.HostScene.load(scene_path("materials")).build()
