@@ -7,7 +7,9 @@
 // DIFFERENT tree — other leaves, another object order — so it sits behind that flag: closest hits have the same t,
 // but which of two objects hit at exactly the same t is reported may differ, and so may the rare hits that the
 // reference's mixed-unit culling (box distances in units of |d|, t in units of 1) drops or keeps depending on the order
-// of the visit.
+// of the visit, and hits on zero-area triangles (their set-up divides by a zero cross product: with infinite edge vectors
+// no barycentric comparison rejects anything, so they are hit wherever a ray meets their plane — if the boxes on the way
+// to their leaf let the ray through, which is the tree's doing).
 #pragma once
 #include <hip/hip_runtime.h>
 

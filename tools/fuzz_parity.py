@@ -122,12 +122,67 @@ def detail(hs, dev, orc, o, d):
             print(f"   pixel ({x},{y}): gpu {img[y, x].tolist()} cpu {ref[y, x].tolist()}")
 
 
+def fuzz_device_bvh(args):
+    rng = np.random.default_rng(args.seed)
+    t0 = time.time()
+    k = bad = rays = built = skipped = 0
+    while time.time() - t0 < args.seconds:
+        hs = random_scene(rng, k)
+        n = 20000
+        o = (rng.normal(size=(n, 3)) * np.array([3, 2, 3]) + np.array([0, 0, -3])).astype(np.float32)
+        d = rng.normal(size=(n, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d = (d * (1.0 + np.abs(rng.normal(size=(n, 1))))).astype(np.float32)
+        if hs.desc.contents.numPrims == 0:
+            k += 1
+            continue
+        dev = capi.device_scene(hs.desc)
+        # Zero-area triangles get infinite edge vectors from the reference's set-up (reciprocals of a zero cross product):
+        # every barycentric comparison is then one with NaN and rejects nothing, so such a triangle is hit wherever a ray
+        # meets its PLANE — far outside its box — provided the traversal reaches its leaf at all, which depends on the
+        # boxes of the tree. Rays that either tree answers with such an object are tree-dependent and left out.
+        dsc = hs.desc.contents
+        rec = np.ctypeslib.as_array(dsc.primHit, shape=(dsc.numPrims, 12))
+        unbounded = np.ctypeslib.as_array(dsc.primOrigIndex, shape=(dsc.numPrims,))[~np.isfinite(rec).all(1)].copy()
+        hs.flatten_without_bvh()
+        lb = capi.device_scene(hs.desc)
+        a, b = dev.trace_closest(o, d), lb.trace_closest(o, d)
+        ha, hb = dev.trace_any(o, d), lb.trace_any(o, d)
+        keep = ~(np.isin(a[0], unbounded) | np.isin(b[0], unbounded))
+        skipped += int((~keep).sum())
+        # a visibility answer cannot say which object it found: with such triangles in the scene it is only checked where
+        # the closest hit is a bounded object (then both trees must say "something is there")
+        found = keep & (a[0] >= 0)
+        ok = same_bits(a[1][keep], b[1][keep]) and bool(ha[found].all()) and bool(hb[found].all()) and \
+            (unbounded.size > 0 or np.array_equal(ha, hb))
+        # which of several objects hit at exactly the same t is reported is the tree's choice; point and normal follow it
+        swapped = float((a[0] != b[0]).mean())
+        rays += 2 * n; built += 1
+        if not ok:
+            bad += 1
+            diff = np.nonzero((a[1].view(np.uint32) != b[1].view(np.uint32)) & keep)[0]
+            print(f"MISMATCH scene {k}: prims {hs.desc.contents.numPrims} t differs on {diff.size} rays, first {diff[:3].tolist()} "
+                  f"host {a[1][diff[:3]].tolist()} device {b[1][diff[:3]].tolist()} ids swapped {swapped:.4f}", flush=True)
+        dev.close(); lb.close()
+        k += 1
+        if k % 500 == 0:
+            print(f"{k} scenes, {built} trees built on the GPU, {rays / 1e6:.1f} M rays, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+    print(f"done: {k} scenes, {built} trees built on the GPU, {rays / 1e6:.1f} M rays, {bad} mismatches; {skipped} rays left out "
+          f"(answered with a zero-area triangle, whose hits depend on the tree)")
+    return 1 if bad else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", type=int, default=-1, help="replay the random stream up to this scene and report on it in detail")
+    ap.add_argument("--device-bvh", action="store_true",
+                    help="instead: the tree built on the GPU against the host-built one on every scene (rays of unit length or longer, "
+                         "for which the answer does not depend on the visit order): bits of t and visibility answers equal")
     args = ap.parse_args()
+    if args.device_bvh:
+        return fuzz_device_bvh(args)
     rng = np.random.default_rng(args.seed)
     t0 = time.time()
     k = bad = rays = diverged = 0
