@@ -24,6 +24,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_amd.h"
@@ -856,6 +857,8 @@ struct RtScene {
   // staging of the trace-only and conversion entry points: grow-only, so a repeated call of the same size allocates nothing
   void *work = nullptr;
   size_t workBytes = 0;
+  void *pinned = nullptr;  // page-locked host staging for results that go to pageable host memory: grow-only as well
+  size_t pinnedBytes = 0;
   hipEvent_t workEvA = nullptr, workEvB = nullptr;
   float lastKernelMs = 0.0f;
   float bvhBuildMs = 0.0f;  // device BVH build of rt_scene_create (0: the scene came with a host-built tree)
@@ -1382,6 +1385,7 @@ void rt_scene_destroy(RtScene *s) {
   if (s->fb) (void)hipFree(s->fb);
   if (s->packed) (void)hipFree(s->packed);
   if (s->work) (void)hipFree(s->work);
+  if (s->pinned) (void)hipHostFree(s->pinned);
   if (s->workEvA) (void)hipEventDestroy(s->workEvA);
   if (s->workEvB) (void)hipEventDestroy(s->workEvB);
   for (auto &ps : s->peers) {
@@ -1423,6 +1427,49 @@ static int ensureWork(RtScene *s, size_t bytes) {
   s->workBytes = bytes;
   return RT_OK;
 }
+static int ensurePinned(RtScene *s, size_t bytes) {
+  if (s->pinnedBytes >= bytes) return RT_OK;
+  if (s->pinned) { (void)hipHostFree(s->pinned); s->pinned = nullptr; s->pinnedBytes = 0; }
+  bytes = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+  HIP_TRY(hipHostMalloc(&s->pinned, bytes, hipHostMallocDefault));
+  s->pinnedBytes = bytes;
+  return RT_OK;
+}
+// Is `p` ordinary (pageable) host memory? The runtime copies into such memory through small staging buffers of its own,
+// at a fraction of the link's rate.
+static bool isPageableHost(const void *p) {
+  hipPointerAttribute_t a{};
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return true; }  // unknown to the runtime
+  return a.type == hipMemoryTypeUnregistered;
+}
+// dst[0 .. bytes) = src, by a few host threads when it is worth starting them
+static void hostCopy(void *dst, const void *src, size_t bytes) {
+  const size_t kPiece = (size_t)1 << 20;
+  const int threads = (int)std::min<size_t>(4, bytes / kPiece);
+  if (threads <= 1) { std::memcpy(dst, src, bytes); return; }
+  std::vector<std::thread> pool;
+  const size_t per = (bytes + threads - 1) / threads;
+  for (int k = 0; k < threads; ++k) {
+    const size_t b = (size_t)k * per, e = std::min(bytes, b + per);
+    if (b < e) pool.emplace_back([=] { std::memcpy(static_cast<char *>(dst) + b, static_cast<const char *>(src) + b, e - b); });
+  }
+  for (auto &t : pool) t.join();
+}
+// A result of `bytes` at device address src to dst, which may be device memory, page-locked or pageable host memory.
+// Large copies into pageable memory go through the scene's page-locked staging (one copy at the link's rate, then host
+// copies) and are complete on return; everything else is queued on `stream` for the caller to wait for.
+static int copyOut(RtScene *s, void *dst, const void *src, size_t bytes, hipStream_t stream) {
+  if (bytes >= ((size_t)1 << 20) && isPageableHost(dst)) {
+    int rc = ensurePinned(s, bytes);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(s->pinned, src, bytes, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    hostCopy(dst, s->pinned, bytes);
+    return RT_OK;
+  }
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, stream));
+  return RT_OK;
+}
 static int ensureWorkEvents(RtScene *s) {
   if (!s->workEvA) HIP_TRY(hipEventCreate(&s->workEvA));
   if (!s->workEvB) HIP_TRY(hipEventCreate(&s->workEvB));
@@ -1451,9 +1498,19 @@ int rt_trace_primary(RtScene *s, int32_t x0, int32_t y0, int32_t w, int32_t h, i
   launchTracePrimary(s, x0, y0, w, h, dPrim, dT, &s->counts->ticket[2].seg[0].next);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->workEvB, s->stream));
-  HIP_TRY(hipMemcpyAsync(primId, dPrim, n * 4, hipMemcpyDefault, s->stream));
-  HIP_TRY(hipMemcpyAsync(t, dT, n * 4, hipMemcpyDefault, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (isPageableHost(primId) && isPageableHost(t)) {
+    // one copy of both arrays into page-locked staging at the link's rate, then plain host copies
+    const size_t tOff = alignUp256((size_t)n * 4);
+    if ((rc = ensurePinned(s, tOff + (size_t)n * 4))) return rc;
+    HIP_TRY(hipMemcpyAsync(s->pinned, s->work, tOff + (size_t)n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    hostCopy(primId, s->pinned, (size_t)n * 4);
+    hostCopy(t, static_cast<const char *>(s->pinned) + tOff, (size_t)n * 4);
+  } else {
+    HIP_TRY(hipMemcpyAsync(primId, dPrim, n * 4, hipMemcpyDefault, s->stream));
+    HIP_TRY(hipMemcpyAsync(t, dT, n * 4, hipMemcpyDefault, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  }
   HIP_TRY(hipEventElapsedTime(&s->lastKernelMs, s->workEvA, s->workEvB));
   return RT_OK;
 }
@@ -1688,7 +1745,7 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
   }
   if (timing) HIP_TRY(hipEventRecord(s->events[totalIdx].b, st));
   HIP_TRY(hipGetLastError());
-  if (rgbaOut) HIP_TRY(hipMemcpyAsync(rgbaOut, s->fb, fbPixels * sizeof(float4), hipMemcpyDefault, st));
+  if (rgbaOut && (rc = copyOut(s, rgbaOut, s->fb, fbPixels * sizeof(float4), st))) return rc;
   Counts hc{};
   HIP_TRY(hipMemcpyAsync(&hc, s->counts, sizeof(Counts), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
@@ -1798,7 +1855,7 @@ int rt_framebuffer_read(RtScene *s, float *rgbaOut) {
   HIP_TRY(hipSetDevice(s->device));
   int64_t n = (int64_t)s->dev.width * s->dev.height;
   if (n > s->fbPixels) return failMsg(RT_ERR_INVALID, "framebuffer is smaller than the current image size");
-  HIP_TRY(hipMemcpyAsync(rgbaOut, s->fb, n * sizeof(float4), hipMemcpyDefault, s->stream));
+  if (int rc = copyOut(s, rgbaOut, s->fb, n * sizeof(float4), s->stream)) return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
   return RT_OK;
 }
@@ -1814,7 +1871,7 @@ int rt_resolve_rgba8(RtScene *s, uint8_t *rgba8Out) {
   uchar4 *d = static_cast<uchar4 *>(s->work);
   k_srgb8<<<gridFor(n), kBlock, 0, s->stream>>>(s->fb, d, (int32_t)n);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(rgba8Out, d, n * 4, hipMemcpyDefault, s->stream));
+  if (int rc = copyOut(s, rgba8Out, d, n * 4, s->stream)) return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
   return RT_OK;
 }
