@@ -1564,20 +1564,45 @@ static int traceRays(RtScene *s, bool any, int64_t n, const float *origins, cons
   float *dP = (!any && point) ? reinterpret_cast<float *>(base + oP) : nullptr;
   float *dN = (!any && normal) ? reinterpret_cast<float *>(base + oN) : nullptr;
   uint32_t *ticket = &s->counts->ticket[2].seg[0].next;
-  HIP_TRY(hipMemcpyAsync(dO, origins, n * 12, hipMemcpyDefault, s->stream));
-  HIP_TRY(hipMemcpyAsync(dD, directions, n * 12, hipMemcpyDefault, s->stream));
+  // Large batches in pageable host memory: rays and results cross the link in one copy each way through page-locked
+  // staging laid out like the device staging; host threads move them between the caller's arrays and the staging.
+  const bool staged = (size_t)n * 24 >= ((size_t)1 << 20) && isPageableHost(origins) && isPageableHost(directions) &&
+                      (!occluded || isPageableHost(occluded)) && (!primId || isPageableHost(primId)) && (!t || isPageableHost(t)) &&
+                      (!point || isPageableHost(point)) && (!normal || isPageableHost(normal));
+  char *pin = nullptr;
+  const size_t inputsEnd = oD + (size_t)n * 12, outputsBegin = oD + alignUp256((size_t)n * 12);
+  if (staged) {
+    if ((rc = ensurePinned(s, off))) return rc;
+    pin = static_cast<char *>(s->pinned);
+    hostCopy(pin + oO, origins, (size_t)n * 12);
+    hostCopy(pin + oD, directions, (size_t)n * 12);
+    HIP_TRY(hipMemcpyAsync(base + oO, pin + oO, inputsEnd - oO, hipMemcpyHostToDevice, s->stream));
+  } else {
+    HIP_TRY(hipMemcpyAsync(dO, origins, n * 12, hipMemcpyDefault, s->stream));
+    HIP_TRY(hipMemcpyAsync(dD, directions, n * 12, hipMemcpyDefault, s->stream));
+  }
   HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(TicketSet), s->stream));
   HIP_TRY(hipEventRecord(s->workEvA, s->stream));
   if (any) k_trace_rays<true><<<persistentGrid(s, n), kBlock, 0, s->stream>>>(s->dev, n, dO, dD, nullptr, nullptr, nullptr, nullptr, dOcc, ticket);
   else k_trace_rays<false><<<persistentGrid(s, n), kBlock, 0, s->stream>>>(s->dev, n, dO, dD, dPrim, dT, dP, dN, nullptr, ticket);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->workEvB, s->stream));
-  if (dOcc) HIP_TRY(hipMemcpyAsync(occluded, dOcc, n, hipMemcpyDefault, s->stream));
-  if (dPrim) HIP_TRY(hipMemcpyAsync(primId, dPrim, n * 4, hipMemcpyDefault, s->stream));
-  if (dT) HIP_TRY(hipMemcpyAsync(t, dT, n * 4, hipMemcpyDefault, s->stream));
-  if (dP) HIP_TRY(hipMemcpyAsync(point, dP, n * 12, hipMemcpyDefault, s->stream));
-  if (dN) HIP_TRY(hipMemcpyAsync(normal, dN, n * 12, hipMemcpyDefault, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (staged && off > outputsBegin) {
+    HIP_TRY(hipMemcpyAsync(pin + outputsBegin, base + outputsBegin, off - outputsBegin, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (dOcc) hostCopy(occluded, pin + oOcc, (size_t)n);
+    if (dPrim) hostCopy(primId, pin + oPrim, (size_t)n * 4);
+    if (dT) hostCopy(t, pin + oT, (size_t)n * 4);
+    if (dP) hostCopy(point, pin + oP, (size_t)n * 12);
+    if (dN) hostCopy(normal, pin + oN, (size_t)n * 12);
+  } else {
+    if (dOcc) HIP_TRY(hipMemcpyAsync(occluded, dOcc, n, hipMemcpyDefault, s->stream));
+    if (dPrim) HIP_TRY(hipMemcpyAsync(primId, dPrim, n * 4, hipMemcpyDefault, s->stream));
+    if (dT) HIP_TRY(hipMemcpyAsync(t, dT, n * 4, hipMemcpyDefault, s->stream));
+    if (dP) HIP_TRY(hipMemcpyAsync(point, dP, n * 12, hipMemcpyDefault, s->stream));
+    if (dN) HIP_TRY(hipMemcpyAsync(normal, dN, n * 12, hipMemcpyDefault, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  }
   HIP_TRY(hipEventElapsedTime(&s->lastKernelMs, s->workEvA, s->workEvB));
   return RT_OK;
 }
