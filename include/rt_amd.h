@@ -29,7 +29,7 @@ extern "C" {
 #define RT_OK 0
 #define RT_ERR_INVALID 1   /* bad argument / unsupported scene (message says which) */
 #define RT_ERR_DEVICE 2    /* HIP runtime error */
-#define RT_ERR_NOMEM 3
+#define RT_ERR_NOMEM 3     /* host memory ran out inside the library (device memory that runs out is RT_ERR_DEVICE) */
 
 /* ---- scene description (host arrays; copied during rt_scene_create) ---------------- */
 

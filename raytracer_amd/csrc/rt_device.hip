@@ -21,8 +21,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -799,6 +801,23 @@ thread_local std::string g_error;
 
 int failMsg(int code, const std::string &msg) { g_error = msg; return code; }
 
+// Called inside a catch (...) of an entry point: no C++ exception leaves the library. Host memory that ran out becomes
+// RT_ERR_NOMEM, anything else RT_ERR_INVALID with what() as the message.
+int caught() noexcept {
+  try {
+    throw;
+  } catch (const std::bad_alloc &) {
+    try { g_error = "out of host memory"; } catch (...) {}
+    return RT_ERR_NOMEM;
+  } catch (const std::exception &e) {
+    try { g_error = std::string("unexpected failure: ") + e.what(); } catch (...) {}
+    return RT_ERR_INVALID;
+  } catch (...) {
+    try { g_error = "unexpected failure"; } catch (...) {}
+    return RT_ERR_INVALID;
+  }
+}
+
 #define HIP_TRY(expr)                                                                                   \
   do {                                                                                                  \
     hipError_t e_ = (expr);                                                                             \
@@ -1341,7 +1360,7 @@ int rt_device_count(void) {
 }
 const char *rt_version(void) { return "raytracer_amd 0.1 (gfx950 wavefront path tracer)"; }
 
-RtScene *rt_scene_create(const RtSceneDesc *desc, int device) {
+RtScene *rt_scene_create(const RtSceneDesc *desc, int device) try {
   if (validateDesc(desc) != RT_OK) return nullptr;
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
@@ -1366,12 +1385,17 @@ RtScene *rt_scene_create(const RtSceneDesc *desc, int device) {
     g_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
     return nullptr;
   }
-  if (buildScene(s.get(), desc) != RT_OK) {
+  int built;
+  try { built = buildScene(s.get(), desc); } catch (...) { built = caught(); }
+  if (built != RT_OK) {
     RtScene *raw = s.release();
     rt_scene_destroy(raw);
     return nullptr;
   }
   return s.release();
+} catch (...) {
+  (void)caught();
+  return nullptr;
 }
 
 void rt_scene_destroy(RtScene *s) {
@@ -1399,7 +1423,7 @@ void rt_scene_destroy(RtScene *s) {
   delete s;
 }
 
-int rt_scene_set_view(RtScene *s, const RtCamera *camera, const RtOptions *options) {
+int rt_scene_set_view(RtScene *s, const RtCamera *camera, const RtOptions *options) try {
   if (!s) return failMsg(RT_ERR_INVALID, "null scene");
   RtCamera cam;
   std::memcpy(cam.eye, s->dev.eye, 12); std::memcpy(cam.forward, s->dev.forward, 12);
@@ -1415,6 +1439,8 @@ int rt_scene_set_view(RtScene *s, const RtCamera *camera, const RtOptions *optio
   }
   setView(s, cam, o);
   return RT_OK;
+} catch (...) {
+  return caught();
 }
 
 // Staging for the trace-only entry points (device side of the host buffers the caller passes). It only ever grows:
@@ -1434,6 +1460,14 @@ static int ensurePinned(RtScene *s, size_t bytes) {
   HIP_TRY(hipHostMalloc(&s->pinned, bytes, hipHostMallocDefault));
   s->pinnedBytes = bytes;
   return RT_OK;
+}
+// Page-locked staging of at least `bytes`, or false: the staging is only a faster route, so a host that cannot lock
+// that much memory gets the plain copies instead of an error.
+static bool havePinned(RtScene *s, size_t bytes) {
+  if (ensurePinned(s, bytes) == RT_OK) return true;
+  (void)hipGetLastError();
+  g_error.clear();
+  return false;
 }
 // Is `p` ordinary (pageable) host memory? The runtime copies into such memory through small staging buffers of its own,
 // at a fraction of the link's rate.
@@ -1459,9 +1493,7 @@ static void hostCopy(void *dst, const void *src, size_t bytes) {
 // Large copies into pageable memory go through the scene's page-locked staging (one copy at the link's rate, then host
 // copies) and are complete on return; everything else is queued on `stream` for the caller to wait for.
 static int copyOut(RtScene *s, void *dst, const void *src, size_t bytes, hipStream_t stream) {
-  if (bytes >= ((size_t)1 << 20) && isPageableHost(dst)) {
-    int rc = ensurePinned(s, bytes);
-    if (rc) return rc;
+  if (bytes >= ((size_t)1 << 20) && isPageableHost(dst) && havePinned(s, bytes)) {
     HIP_TRY(hipMemcpyAsync(s->pinned, src, bytes, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     hostCopy(dst, s->pinned, bytes);
@@ -1483,7 +1515,7 @@ static void launchTracePrimary(RtScene *s, int32_t x0, int32_t y0, int32_t w, in
   k_trace_primary<<<persistentGrid(s, waves * 64), kBlock, 0, s->stream>>>(s->dev, x0, y0, w, h, outPrim, outT, ticket);
 }
 
-int rt_trace_primary(RtScene *s, int32_t x0, int32_t y0, int32_t w, int32_t h, int32_t *primId, float *t) {
+int rt_trace_primary(RtScene *s, int32_t x0, int32_t y0, int32_t w, int32_t h, int32_t *primId, float *t) try {
   if (!s || !primId || !t) return failMsg(RT_ERR_INVALID, "null argument");
   if (w <= 0 || h <= 0) return failMsg(RT_ERR_INVALID, "empty rectangle");
   HIP_TRY(hipSetDevice(s->device));
@@ -1498,10 +1530,9 @@ int rt_trace_primary(RtScene *s, int32_t x0, int32_t y0, int32_t w, int32_t h, i
   launchTracePrimary(s, x0, y0, w, h, dPrim, dT, &s->counts->ticket[2].seg[0].next);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->workEvB, s->stream));
-  if (isPageableHost(primId) && isPageableHost(t)) {
+  const size_t tOff = alignUp256((size_t)n * 4);
+  if (isPageableHost(primId) && isPageableHost(t) && havePinned(s, tOff + (size_t)n * 4)) {
     // one copy of both arrays into page-locked staging at the link's rate, then plain host copies
-    const size_t tOff = alignUp256((size_t)n * 4);
-    if ((rc = ensurePinned(s, tOff + (size_t)n * 4))) return rc;
     HIP_TRY(hipMemcpyAsync(s->pinned, s->work, tOff + (size_t)n * 4, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     hostCopy(primId, s->pinned, (size_t)n * 4);
@@ -1513,9 +1544,11 @@ int rt_trace_primary(RtScene *s, int32_t x0, int32_t y0, int32_t w, int32_t h, i
   }
   HIP_TRY(hipEventElapsedTime(&s->lastKernelMs, s->workEvA, s->workEvB));
   return RT_OK;
+} catch (...) {
+  return caught();
 }
 
-int rt_trace_primary_static(RtScene *s, int32_t x0, int32_t y0, int32_t w, int32_t h, int32_t *primId, float *t) {
+int rt_trace_primary_static(RtScene *s, int32_t x0, int32_t y0, int32_t w, int32_t h, int32_t *primId, float *t) try {
   if (!s || !primId || !t) return failMsg(RT_ERR_INVALID, "null argument");
   if (w <= 0 || h <= 0) return failMsg(RT_ERR_INVALID, "empty rectangle");
   const int64_t n = (int64_t)w * h;
@@ -1536,6 +1569,8 @@ int rt_trace_primary_static(RtScene *s, int32_t x0, int32_t y0, int32_t w, int32
   HIP_TRY(hipMemcpyAsync(t, dT, n * 4, hipMemcpyDefault, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   return RT_OK;
+} catch (...) {
+  return caught();
 }
 
 int64_t rt_trace_primary_static_max_pixels(void) { return kStaticTraceMaxPixels; }
@@ -1568,11 +1603,10 @@ static int traceRays(RtScene *s, bool any, int64_t n, const float *origins, cons
   // staging laid out like the device staging; host threads move them between the caller's arrays and the staging.
   const bool staged = (size_t)n * 24 >= ((size_t)1 << 20) && isPageableHost(origins) && isPageableHost(directions) &&
                       (!occluded || isPageableHost(occluded)) && (!primId || isPageableHost(primId)) && (!t || isPageableHost(t)) &&
-                      (!point || isPageableHost(point)) && (!normal || isPageableHost(normal));
+                      (!point || isPageableHost(point)) && (!normal || isPageableHost(normal)) && havePinned(s, off);
   char *pin = nullptr;
   const size_t inputsEnd = oD + (size_t)n * 12, outputsBegin = oD + alignUp256((size_t)n * 12);
   if (staged) {
-    if ((rc = ensurePinned(s, off))) return rc;
     pin = static_cast<char *>(s->pinned);
     hostCopy(pin + oO, origins, (size_t)n * 12);
     hostCopy(pin + oD, directions, (size_t)n * 12);
@@ -1608,16 +1642,20 @@ static int traceRays(RtScene *s, bool any, int64_t n, const float *origins, cons
 }
 
 int rt_trace_closest(RtScene *s, int64_t n, const float *origins, const float *directions, int32_t *primId, float *t, float *point,
-                     float *normal) {
+                     float *normal) try {
   return traceRays(s, false, n, origins, directions, primId, t, point, normal, nullptr);
+} catch (...) {
+  return caught();
 }
 
-int rt_trace_any(RtScene *s, int64_t n, const float *origins, const float *directions, uint8_t *occluded) {
+int rt_trace_any(RtScene *s, int64_t n, const float *origins, const float *directions, uint8_t *occluded) try {
   if (!occluded) return failMsg(RT_ERR_INVALID, "null argument");
   return traceRays(s, true, n, origins, directions, nullptr, nullptr, nullptr, nullptr, occluded);
+} catch (...) {
+  return caught();
 }
 
-int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats *stats) {
+int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats *stats) try {
   if (!s || !params) return failMsg(RT_ERR_INVALID, "null argument");
   if (params->rngMode != RT_RNG_COUNTER) return failMsg(RT_ERR_INVALID, "the HIP library only implements RT_RNG_COUNTER");
   if (params->partCount > 1 && (params->partIndex < 0 || params->partIndex >= params->partCount))
@@ -1806,11 +1844,13 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
     stats->msResolve = ms[CAT_RESOLVE];
   }
   return RT_OK;
+} catch (...) {
+  return caught();
 }
 
 const float *rt_framebuffer_device(RtScene *s) { return s ? reinterpret_cast<const float *>(s->fb) : nullptr; }
 
-int rt_framebuffer_gather(RtScene *dst, RtScene *const *srcs, int32_t numSrcs) {
+int rt_framebuffer_gather(RtScene *dst, RtScene *const *srcs, int32_t numSrcs) try {
   if (!dst || (numSrcs > 0 && !srcs) || numSrcs < 0) return failMsg(RT_ERR_INVALID, "null argument");
   if (!dst->fb) return failMsg(RT_ERR_INVALID, "rt_render has not run on the destination scene");
   const int64_t n = (int64_t)dst->dev.width * dst->dev.height;
@@ -1866,15 +1906,19 @@ int rt_framebuffer_gather(RtScene *dst, RtScene *const *srcs, int32_t numSrcs) {
   }
   HIP_TRY(hipStreamSynchronize(dst->stream));
   return RT_OK;
+} catch (...) {
+  return caught();
 }
 
-int rt_framebuffer_add(RtScene *dst, RtScene *src) {
+int rt_framebuffer_add(RtScene *dst, RtScene *src) try {
   if (!dst || !src || dst == src) return failMsg(RT_ERR_INVALID, "rt_framebuffer_add needs two different scenes");
   RtScene *one[1] = {src};
   return rt_framebuffer_gather(dst, one, 1);
+} catch (...) {
+  return caught();
 }
 
-int rt_framebuffer_read(RtScene *s, float *rgbaOut) {
+int rt_framebuffer_read(RtScene *s, float *rgbaOut) try {
   if (!s || !rgbaOut) return failMsg(RT_ERR_INVALID, "null argument");
   if (!s->fb) return failMsg(RT_ERR_INVALID, "rt_render has not run on this scene");
   HIP_TRY(hipSetDevice(s->device));
@@ -1883,9 +1927,11 @@ int rt_framebuffer_read(RtScene *s, float *rgbaOut) {
   if (int rc = copyOut(s, rgbaOut, s->fb, n * sizeof(float4), s->stream)) return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
   return RT_OK;
+} catch (...) {
+  return caught();
 }
 
-int rt_resolve_rgba8(RtScene *s, uint8_t *rgba8Out) {
+int rt_resolve_rgba8(RtScene *s, uint8_t *rgba8Out) try {
   if (!s || !rgba8Out) return failMsg(RT_ERR_INVALID, "null argument");
   if (!s->fb) return failMsg(RT_ERR_INVALID, "rt_render has not run on this scene");
   HIP_TRY(hipSetDevice(s->device));
@@ -1899,6 +1945,8 @@ int rt_resolve_rgba8(RtScene *s, uint8_t *rgba8Out) {
   if (int rc = copyOut(s, rgba8Out, d, n * 4, s->stream)) return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
   return RT_OK;
+} catch (...) {
+  return caught();
 }
 
 float rt_last_trace_kernel_ms(RtScene *s) { return s ? s->lastKernelMs : 0.0f; }

@@ -96,6 +96,7 @@ class TreeBuilder {
     std::mutex m;
     std::condition_variable cv;
     int busy = 0;
+    WorkerFailure failure;
     auto worker = [&]() {
       std::unique_lock<std::mutex> lock(m);
       while (true) {
@@ -105,19 +106,42 @@ class TreeBuilder {
         ++busy;
         lock.unlock();
         bool split = false;
-        if (nodes_[(size_t)n].count >= kTaskNode) split = splitNode(n, false);
-        else buildSubtree(n);
+        try {
+          if (nodes_[(size_t)n].count >= kTaskNode) split = splitNode(n, false);
+          else buildSubtree(n);
+        } catch (...) {  // kept for the calling thread; the queue is emptied so that every worker leaves
+          failure.record();
+          lock.lock();
+          pieces.clear();
+          --busy;
+          cv.notify_all();
+          return;
+        }
         lock.lock();
-        if (split) { pieces.push_back(nodes_[(size_t)n].right); pieces.push_back(nodes_[(size_t)n].left); }
+        if (split) {
+          try {
+            pieces.push_back(nodes_[(size_t)n].right); pieces.push_back(nodes_[(size_t)n].left);
+          } catch (...) {
+            failure.record();
+            pieces.clear();
+            split = false;
+          }
+        }
         --busy;
         cv.notify_all();
       }
     };
     const int workers = std::max(1, std::min(hostThreads(), (int)prims_.size() / kTaskNode + 1));
-    if (workers <= 1) { worker(); return; }
+    if (workers <= 1) { worker(); failure.rethrow(); return; }
+    // the calling thread is one of the workers; with fewer threads than asked for, those there are share the work
     std::vector<std::thread> pool;
-    for (int w = 0; w < workers; ++w) pool.emplace_back(worker);
+    pool.reserve((size_t)workers);
+    for (int w = 1; w < workers; ++w) {
+      try { pool.emplace_back(worker); } catch (const std::system_error &) { break; }
+    }
+    worker();
     for (auto &t : pool) t.join();
+    failure.rethrow();
   }
 
   // pre-order numbering; returns the node count
