@@ -468,3 +468,16 @@ def test_philox_known_answers_and_stream_injectivity():
         assert list(got) == list(draws[i])
     assert len(np.unique(words, axis=0)) == len(pairs), "two camera samples share a random stream"
     assert len(np.unique(draws, axis=0)) == len(pairs)
+
+
+def test_host_parallel_loops_cover_every_index_and_hand_exceptions_to_the_caller(tmp_path):
+    """The loops every parallel step of the host library runs on (raytracer_amd/host/rth_threads.h): each index exactly
+    once at 1, 2, 8 and 16 threads, chunk numbers in data order, and an exception thrown on a worker thread arrives on
+    the calling thread (instead of ending the process) once all workers have stopped."""
+    exe = str(tmp_path / "threads_check")
+    libdir = os.path.join(REPO, "raytracer_amd")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-pthread", "-I" + os.path.join(libdir, "host"),
+                    os.path.join(REPO, "tests", "cpp", "threads_check.cpp"), "-L" + libdir, "-lrt_host",
+                    "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
