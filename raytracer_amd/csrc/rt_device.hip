@@ -26,6 +26,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -1482,11 +1483,15 @@ static void hostCopy(void *dst, const void *src, size_t bytes) {
   const int threads = (int)std::min<size_t>(4, bytes / kPiece);
   if (threads <= 1) { std::memcpy(dst, src, bytes); return; }
   std::vector<std::thread> pool;
+  pool.reserve((size_t)threads);
   const size_t per = (bytes + threads - 1) / threads;
-  for (int k = 0; k < threads; ++k) {
+  auto piece = [=](size_t b, size_t e) { std::memcpy(static_cast<char *>(dst) + b, static_cast<const char *>(src) + b, e - b); };
+  for (int k = 1; k < threads; ++k) {
     const size_t b = (size_t)k * per, e = std::min(bytes, b + per);
-    if (b < e) pool.emplace_back([=] { std::memcpy(static_cast<char *>(dst) + b, static_cast<const char *>(src) + b, e - b); });
+    if (b >= e) break;
+    try { pool.emplace_back(piece, b, e); } catch (const std::system_error &) { piece(b, e); }  // no thread to be had: copied here
   }
+  piece(0, std::min(bytes, per));  // the calling thread takes the first piece
   for (auto &t : pool) t.join();
 }
 // A result of `bytes` at device address src to dst, which may be device memory, page-locked or pageable host memory.
