@@ -74,11 +74,15 @@ struct Counts {
 };
 
 struct PathBuf {
-  float4 *rayO, *rayD, *beta, *L;
+  float4 *rayO, *rayD, *L;
+  // Path weight. A bounce reads beta[bounce & 1] (what the path carried into the bounce; all ones at bounce 0 and not
+  // stored) and writes beta[(bounce + 1) & 1]: k_direct, which runs after k_shade has updated the weight, still finds the
+  // value from before the update without a copy being kept for it.
+  float4 *beta[2];
   uint32_t *rng;
   float *hitT;
   int32_t *hitPrim;
-  float4 *shPoint, *shColor, *shWeight;
+  float4 *shPoint, *shColor;
   float4 *envWi;   // [numEnvLights][P] hemisphere direction drawn for each environment light
   float4 *lightC;  // [numLights][P] what each light contributes if it turns out to be visible
   uint32_t *qA, *qB, *qHit;
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
     // the path's random stream is a function of its pixel and sample index; only the draw count is stored
     const uint32_t pixPos = slot / (uint32_t)B.spp, sampleInPass = slot - pixPos * (uint32_t)B.spp;
     rng = rngInit(seed, (uint32_t)pixList[B.active ? B.active[pixPos] : (int32_t)pixPos], (uint32_t)sampleBase + sampleInPass, B.rng[slot]);
-    const float4 beta4 = bounce == 0 ? make_float4(1, 1, 1, 1) : B.beta[slot];  // bounce is uniform
+    const float4 beta4 = bounce == 0 ? make_float4(1, 1, 1, 1) : B.beta[bounce & 1][slot];  // bounce is uniform
     V3 o = v3(o4.x, o4.y, o4.z), d = v3(d4.x, d4.y, d4.z);
     const bool onObject = prim >= 0 && prim < S.numPrims;
     ObjectData od;
@@ -321,8 +325,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
       // Inputs of the direct-light term L += beta * (getColor(biased) * sum_lights intensity), finished by k_direct once
       // visibility is known.
       RGBA color = getColor(S, prim, biased, od);
-      B.shColor[slot] = f4(color);
-      if (bounce > 0) B.shWeight[slot] = f4(beta);  // (1, 1, 1, 1) at the first bounce: k_direct knows
+      B.shColor[slot] = f4(color);  // the weight k_direct needs is beta[bounce & 1], which this kernel only reads
     }
   }
   // ------------------------------------------------------------------ part 2: the lights, in scene order
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
       }
     }
     if (bounce + 1 < S.maxBounces) {  // nothing reads them after the last bounce
-      B.beta[slot] = f4(beta);
+      B.beta[(bounce + 1) & 1][slot] = f4(beta);
       B.rng[slot] = rng.draws;
     }
   }
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(DevScene S, PathBuf B, int32_
   RGBA Lsum = rgba(0, 0, 0, 1);  // `RGBAColor L;`
   for (int k = 0; k < S.numLights; ++k) addAssign(Lsum, rgba(B.lightC[(int64_t)k * B.P + slot]));
   RGBA L = bounce == 0 ? rgba(0, 0, 0, 0) : rgba(B.L[slot]);  // a path's L is first written at its first bounce
-  const RGBA weight = bounce == 0 ? rgba(1, 1, 1, 1) : rgba(B.shWeight[slot]);
+  const RGBA weight = bounce == 0 ? rgba(1, 1, 1, 1) : rgba(B.beta[bounce & 1][slot]);  // the weight the path carried into the bounce
   addAssign(L, weight * (rgba(B.shColor[slot]) * Lsum));
   B.L[slot] = f4(L);
 }
@@ -1272,11 +1275,11 @@ int ensureRenderBuffers(RtScene *s, int64_t P, int64_t npix, int64_t fbPixels) {
   char *base = static_cast<char *>(s->arena);
   b.rayO = reinterpret_cast<float4 *>(base); base += f4b;
   b.rayD = reinterpret_cast<float4 *>(base); base += f4b;
-  b.beta = reinterpret_cast<float4 *>(base); base += f4b;
+  b.beta[0] = reinterpret_cast<float4 *>(base); base += f4b;
   b.L = reinterpret_cast<float4 *>(base); base += f4b;
   b.shPoint = reinterpret_cast<float4 *>(base); base += f4b;
   b.shColor = reinterpret_cast<float4 *>(base); base += f4b;
-  b.shWeight = reinterpret_cast<float4 *>(base); base += f4b;
+  b.beta[1] = reinterpret_cast<float4 *>(base); base += f4b;
   b.envWi = reinterpret_cast<float4 *>(base); base += f4b * std::max(1, s->numEnvLights);
   b.lightC = reinterpret_cast<float4 *>(base); base += f4b * std::max(1, s->dev.numLights);
   b.rng = reinterpret_cast<uint32_t *>(base); base += (size_t)cap * 4;
