@@ -245,6 +245,21 @@ enum ShadowCode {
   SHADOW_ZERO = 3     // the unshadowed contribution is exactly (0, 0, 0): visible or not, it adds the same nothing
 };
 
+// The code k_shade left for (queue position pos, light k).
+RT_DEV int shadowCodeAt(const PathBuf &B, int k, uint32_t pos) {
+  const uint4 w = B.shadowCode[(int64_t)k * B.rowsCap + (pos >> 6)];
+  const uint32_t bit = pos & 31u;
+  return (int)((((pos & 32u) ? w.y : w.x) >> bit) & 1u) | (int)(((((pos & 32u) ? w.w : w.z) >> bit) & 1u) << 1);
+}
+// Contributions that are not stored because the code says what they are: a light hidden by a plane contributes
+// RGBAColor(0, 0, 0, 1); a contribution of exactly zero is (0, 0, 0, alpha of the light's colour), the scalar factors
+// leave alpha alone (src/image/PNG.cpp:32-37) - unless the colour came out of an environment map, whose alpha is the
+// texel's. (A stored zero may be -0; added to a sum that starts at +0 and is never -0, both zeros give the same bits.)
+RT_DEV bool contributionImplied(const DevLight &l, int code) {
+  return code == SHADOW_PLANE || (code == SHADOW_ZERO && !(l.type == RT_LIGHT_ENVIRONMENT && l.texture >= 0));
+}
+RT_DEV RGBA impliedContribution(const DevLight &l, int code) { return rgba(0, 0, 0, code == SHADOW_PLANE ? 1.0f : l.color[3]); }
+
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 5
 #endif
@@ -374,7 +389,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
           }
         }
       }
-      B.lightC[(int64_t)k * B.P + slot] = c4;
+      if (!contributionImplied(l, code)) B.lightC[(int64_t)k * B.P + slot] = c4;
       if (code == SHADOW_TRACE) {  // what k_shadow reads of a query it traces
         anyTraced = true;
         if (l.type == RT_LIGHT_ENVIRONMENT) B.envWi[(int64_t)l.envSlot * B.P + slot] = make_float4(toLight.x, toLight.y, toLight.z, 0);
@@ -412,7 +427,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
   }
   uint32_t qh, qn;
   queueSlots2(&B.counts->nHit, isHit, continues, qh, qn);
-  if (isHit) B.qHit[qh] = slot;
+  if (isHit && S.numLights == 0) B.qHit[qh] = slot;  // with lights, k_direct finds the hits through the visibility codes
   if (continues) queueNext[qn] = slot;
 }
 
@@ -432,9 +447,7 @@ struct ShadowSource {
   RT_DEV uint32_t total() const { return nActive * (uint32_t)S.numLights; }
   RT_DEV int classify(uint32_t idx) const {
     const uint32_t k = idx / nActive, pos = idx - k * nActive;
-    const uint4 w = B.shadowCode[(int64_t)k * B.rowsCap + (pos >> 6)];
-    const uint32_t bit = pos & 31u;
-    return (int)((((pos & 32u) ? w.y : w.x) >> bit) & 1u) | (int)(((((pos & 32u) ? w.w : w.z) >> bit) & 1u) << 1);  // a ShadowCode
+    return shadowCodeAt(B, (int)k, pos);
   }
   RT_DEV void passedOver(uint32_t idx, int code) {
     const bool point = S.lights[idx / nActive].type == RT_LIGHT_POINT;
@@ -521,12 +534,27 @@ __global__ RT_TRAV_ATTR void k_shadow_then_extend(DevScene S, PathBuf B, const u
 }
 
 // L += beta * (getColor(point) * sum over lights, in scene order) — src/scene/raytracer.cpp:198-206, 231
-__global__ __launch_bounds__(kBlock) void k_direct(DevScene S, PathBuf B, int32_t bounce) {
+// Runs over the queue k_shade ran over: the codes it left say which positions are hits (a hit has a code for every
+// light) and which contributions were not stored because the code implies them. A scene without lights has no codes;
+// its hits (the sum is RGBAColor(0, 0, 0, 1) then, which still raises alpha) come from the hit queue.
+__global__ __launch_bounds__(kBlock) void k_direct(DevScene S, PathBuf B, const uint32_t *queue, int32_t bounce) {
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= B.counts->nHit) return;
-  uint32_t slot = B.qHit[i];
+  uint32_t slot;
   RGBA Lsum = rgba(0, 0, 0, 1);  // `RGBAColor L;`
-  for (int k = 0; k < S.numLights; ++k) addAssign(Lsum, rgba(B.lightC[(int64_t)k * B.P + slot]));
+  if (S.numLights == 0) {
+    if (i >= B.counts->nHit) return;
+    slot = B.qHit[i];
+  } else {
+    if (i >= B.counts->nActive) return;
+    int code = shadowCodeAt(B, 0, i);
+    if (code == SHADOW_NONE) return;  // a miss
+    slot = queue[i];
+    for (int k = 0; k < S.numLights; ++k) {
+      if (k > 0) code = shadowCodeAt(B, k, i);
+      const DevLight &l = S.lights[k];
+      addAssign(Lsum, contributionImplied(l, code) ? impliedContribution(l, code) : rgba(B.lightC[(int64_t)k * B.P + slot]));
+    }
+  }
   RGBA L = bounce == 0 ? rgba(0, 0, 0, 0) : rgba(B.L[slot]);  // a path's L is first written at its first bounce
   const RGBA weight = bounce == 0 ? rgba(1, 1, 1, 1) : rgba(B.beta[bounce & 1][slot]);  // the weight the path carried into the bounce
   addAssign(L, weight * (rgba(B.shColor[slot]) * Lsum));
@@ -1786,7 +1814,7 @@ int rt_render(RtScene *s, const RtRenderParams *params, float *rgbaOut, RtStats 
         ++launchesShadow;
       }
       if ((rc = beginEvent(s, CAT_DIRECT, timing))) return rc;
-      k_direct<<<grid, kBlock, 0, st>>>(S, B, bounce);
+      k_direct<<<grid, kBlock, 0, st>>>(S, B, qCur, bounce);
       if ((rc = endEvent(s, timing))) return rc;
       k_advance<<<1, 1, 0, st>>>(B, s->numPointLights, s->numAnyLights);
       std::swap(qCur, qNext);
