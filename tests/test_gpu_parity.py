@@ -537,6 +537,41 @@ def test_empty_and_degenerate_scenes(tmp_path):
             assert psnr(img[..., :3], ref[..., :3]) >= PSNR_MIN_DB
 
 
+@pytest.mark.parametrize("lights", ["none", "alpha"])
+def test_light_contributions_that_are_implied_not_stored(lights):
+    """The direct-light sum (src/scene/raytracer.cpp:198-206) when the library does not store a light's contribution:
+    hidden by a plane it is RGBAColor(0, 0, 0, 1), exactly zero it is (0, 0, 0, alpha of the light's colour), and the
+    alpha travels into the pixel through max() (src/image/PNG.cpp:79-85). Lights whose colour has alpha 0.25 and 3, an
+    environment map whose texels have alpha 2 (its zero contributions are stored: the alpha is the texel's); and a scene
+    without lights, where the sum is RGBAColor(0, 0, 0, 1) at every hit."""
+    hs = capi.HostScene.new(96, 64)
+    mats = [0, hs.add_material(capi.RT_MAT_PLASTIC, Kd=0.7, Kr=0.3, eta=1.5, roughness=0.2), hs.add_material(capi.RT_MAT_MIRROR, Kr=0.9, eta=1.5)]
+    rng = np.random.default_rng(5)
+    for k in range(12):
+        hs.add_sphere(tuple(rng.normal(size=3) * 1.2 + np.array([0, 0, -4])), float(rng.uniform(0.2, 0.8)),
+                      color=tuple(rng.uniform(0.2, 1, size=3)) + (float(rng.choice([1.0, 0.5])),), material=mats[k % 3])
+    hs.add_plane((0, 1, 0), 1.5, color=(0.8, 0.8, 0.7, 1.0))
+    hs.add_plane((0, 0, 1), 7.0, color=(0.5, 0.6, 0.8, 0.75))
+    if lights == "alpha":
+        yy, xx = np.mgrid[0:16, 0:32]
+        env = np.stack([0.3 + 0.3 * np.sin(xx / 5.0), np.where(yy < 8, 0.0, 0.4), 0.2 + 0.0 * xx, np.full(xx.shape, 2.0)], -1)
+        env[:4] = (0.0, 0.0, 0.0, 2.0)  # a black band: zero contributions whose alpha is the texel's
+        hs.add_light(capi.RT_LIGHT_POINT, color=(5, 5, 4, 0.25), v=(1.5, 2.0, -2.0))
+        hs.add_light(capi.RT_LIGHT_DISTANT, color=(0.4, 0.4, 0.5, 3.0), v=(-1, 1, 0.5))
+        hs.add_light(capi.RT_LIGHT_ENVIRONMENT, color=(0.2, 0.2, 0.2, 1.0), radius=10.0, texture=hs.add_texture(env))
+        hs.add_light(capi.RT_LIGHT_ENVIRONMENT, color=(0.0, 0.1, 0.0, 0.5), radius=10.0)
+    hs.set_camera(eye=(0, 0, 0), forward=(0, 0, -1), up=(0, 1, 0))
+    hs.set_options(96, 64, maxBounces=4, numRays=8)
+    hs = hs.build()
+    dev, orc = capi.device_scene(hs.desc), oracle_scene(hs.desc)
+    img, st = dev.render(seed=3)
+    ref, ost = orc.render(seed=3)
+    assert np.array_equal(img[..., 3], ref[..., 3])
+    assert psnr(img[..., :3], ref[..., :3]) >= PSNR_MIN_DB
+    if lights == "alpha":
+        assert st.raysSkipped > 0 and st.raysPlaneAnswered > 0  # both implied kinds occur
+
+
 def test_hip_library_rejects_what_it_cannot_do(scenes):
     _, dev, _ = scenes("config1")
     with pytest.raises(RuntimeError, match="RT_RNG_COUNTER"):

@@ -32,7 +32,7 @@ def random_scene(rng, k):
             th, tw = int(rng.integers(2, 40)), int(rng.integers(2, 40))
             yy, xx = np.mgrid[0:th, 0:tw]
             img = np.stack([0.5 + 0.4 * np.sin(xx / tw * 6 + rng.uniform(0, 6)), 0.5 + 0.4 * np.cos(yy / th * 5), 0.3 + 0.2 * np.sin((xx + yy) / 9.0),
-                            np.ones_like(xx, dtype=float)], -1)
+                            np.full(xx.shape, float(rng.choice([1.0, 1.0, 0.5, 2.0])))], -1)
             texs.append(hs.add_texture(img))
     pick_tex = lambda: int(rng.choice(texs)) if texs and rng.random() < 0.6 else -1
     ntri = int(rng.choice([0, 1, 3, 50, 700, 5000]))
@@ -56,12 +56,13 @@ def random_scene(rng, k):
                      texture=pick_tex())
     kinds = rng.choice([capi.RT_LIGHT_POINT, capi.RT_LIGHT_DISTANT, capi.RT_LIGHT_ENVIRONMENT], size=int(rng.integers(0, 4)))
     for t in kinds:
+        la = float(rng.choice([1.0, 1.0, 0.25, 3.0]))  # alpha of the light's colour: it reaches the pixel's alpha through max()
         if t == capi.RT_LIGHT_POINT:  # some bulbs closer than 1 unit to the geometry (|d| < 1 visibility rays)
-            hs.add_light(t, color=tuple(rng.uniform(0, 6, size=3)) + (1.0,), v=tuple(rng.normal(size=3) * 0.7 + np.array([0, 0, -3])))
+            hs.add_light(t, color=tuple(rng.uniform(0, 6, size=3)) + (la,), v=tuple(rng.normal(size=3) * 0.7 + np.array([0, 0, -3])))
         elif t == capi.RT_LIGHT_DISTANT:
-            hs.add_light(t, color=tuple(rng.uniform(0, 1, size=3)) + (1.0,), v=tuple(rng.normal(size=3)))
+            hs.add_light(t, color=tuple(rng.uniform(0, 1, size=3)) + (la,), v=tuple(rng.normal(size=3)))
         else:
-            hs.add_light(t, color=tuple(rng.uniform(0, 0.5, size=3)) + (1.0,), radius=float(rng.uniform(5, 20)), texture=pick_tex())
+            hs.add_light(t, color=tuple(rng.uniform(0, 0.5, size=3)) + (la,), radius=float(rng.uniform(5, 20)), texture=pick_tex())
     fwd = rng.normal(size=3) * 0.2 + np.array([0, 0, -1])
     hs.set_camera(eye=tuple(rng.normal(size=3) * 0.3), forward=tuple(fwd), up=(0, 1, 0))
     mode = k % 4
