@@ -319,7 +319,6 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
   float tBest = kInf, bulbDist = 0.0f;
   float tPlane = kInf;     // closest plane along the ray (found when the query was prepared)
   int32_t planeBest = -1;
-  float cullD = kInf;  // TRAV_POINT_LIGHT: boxes entered beyond this distance (in units of |d|) cannot matter, see below
   int32_t primBest = -1, cur = 0, pi = 0, pe = 0;
   int sp = 0, lo = 0, mode = TRAV_CLOSEST;
   bool finite = true;
@@ -362,7 +361,7 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
       uint2 *slot = stackCol + (sp & (K - 1)) * BLOCK;
       if (sp < lo) { lo = sp; *slot = spill[sp]; }
       uint2 e = *slot;
-      if (__uint_as_float(e.x) < (RUNTIME_MODE ? __builtin_fminf(tBest, cullD) : tBest)) { enter((int32_t)e.y); break; }
+      if (__uint_as_float(e.x) < tBest) { enter((int32_t)e.y); break; }
     }
   };
   // The end of a query. The closest plane was found when the query was prepared; the reference tests the planes after
@@ -481,19 +480,16 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
           if (planeAnswers) {
             deliver(qitem, true, qmode, qtPlane, S.numPrims + qplane, qtPlane, qplane, qo, qnd);
           } else {
-            // A point-light query only asks whether the closest hit lies nearer than the bulb. With |d| = bulbDist >= 1
-            // the reference's culling is conservative (box distances are in units of |d|, t in units of 1, so a box is
-            // never farther than its distance says) and its closest hit is the true one; every object in a box entered
-            // beyond the bulb (distance > 1 in units of |d|, plus a 1 % margin for rounding) is hit beyond the bulb, which
-            // answers the question like no hit at all. Such boxes are skipped. For bulbDist < 1 the reference's culling
-            // can drop nearer hits depending on what it visited before, so nothing is skipped then.
-            const float qcull = (RUNTIME_MODE && qmode == TRAV_POINT_LIGHT && qbulb >= 1.0f) ? 1.01f : kInf;
+            // A point-light query only asks whether the closest hit lies nearer than the bulb, and ends as soon as an
+            // accepted hit is (RT_PRIM_STEP). Boxes are NOT culled against the bulb's distance: the slab test is no safe
+            // lower bound for that (a ray almost parallel to a flat box: the rounding of (box - origin) times a huge
+            // reciprocal moves the entry distance by several percent), and a box culled by mistake loses an occluder.
             if (S.rootRef != kNoBvh) {
               qinv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // src/acceleration/BVH.cpp:293
               qfinite = S.boxesFinite && isfinite(qinv.x) && isfinite(qinv.y) && isfinite(qinv.z) && qinv.x != 0 && qinv.y != 0 &&
                         qinv.z != 0 && isfinite(qo.x) && isfinite(qo.y) && isfinite(qo.z);
               float rootDist = intersectAABB(qo, qinv, S.rootMin[0], S.rootMin[1], S.rootMin[2], S.rootMax[0], S.rootMax[1], S.rootMax[2]);
-              if (rootDist < qcull) qfirst = S.rootRef;
+              if (rootDist < kInf) qfirst = S.rootRef;
             }
             if (qfirst == kNoBvh) deliver(qitem, false, qmode, kInf, -1, qtPlane, qplane, qo, qnd);  // nothing to traverse
             else pooled = true;
@@ -534,7 +530,6 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
           planeBest = RUNTIME_MODE ? -1 : (int32_t)(packed & 0xffffu) - 1;
           mode = (int)((packed >> 16) & 0xfu);
           finite = ((packed >> 20) & 1u) != 0u;
-          if (RUNTIME_MODE) cullD = (mode == TRAV_POINT_LIGHT && bulbDist >= 1.0f) ? 1.01f : kInf;
           tBest = kInf; primBest = -1; sp = 0; lo = 0;
           enter(first);
         }
@@ -564,7 +559,7 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
           const float4 *N = reinterpret_cast<const float4 *>(nodeBase + ((uint32_t)cur << 6));
           a = N[0]; b = N[1]; c = N[2];
           r = reinterpret_cast<const int4 *>(N)[3];
-          const float lim = RUNTIME_MODE ? __builtin_fminf(tBest, cullD) : tBest;
+          const float lim = tBest;
           if (waveExact) innerStep<true, K, BLOCK>(a, b, c, r, o, inv, lim, stackCol, spill, sp, lo, cur, pi, pe, op);  // wave-uniform: valid for every ray, just slower
           else innerStep<false, K, BLOCK>(a, b, c, r, o, inv, lim, stackCol, spill, sp, lo, cur, pi, pe, op);
         }

@@ -192,7 +192,8 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DevScene S, PathBuf B, const 
     // never enters the queue (or a scene without a single bounce) needs its L written here.
     if (!alive || S.maxBounces <= 0) B.L[i] = make_float4(0, 0, 0, 0);
     if (alive) {
-      B.rayO[i] = make_float4(o.x, o.y, o.z, 0);
+      // without a lens every camera ray starts at the eye: the first bounce's kernels take it from the scene
+      if (S.cameraMode == 2) B.rayO[i] = make_float4(o.x, o.y, o.z, 0);
       B.rayD[i] = make_float4(d.x, d.y, d.z, 0);
     }
   }
@@ -211,11 +212,18 @@ struct ExtendSource {
   const PathBuf &B;
   const uint32_t *queue;
   const uint32_t *count;  // length of the queue: nActive, or nNext when the next bounce's queue is traced before the swap
+  const float *eye;       // camera rays of a camera without a lens: their common origin (k_raygen has not stored it); else nullptr
   RT_DEV uint32_t total() const { return *count; }
   RT_DEV uint32_t fetch(uint32_t idx, V3 &o, V3 &d, int &mode, float &bulbDist) const {
     uint32_t slot = queue[idx];
-    float4 o4 = B.rayO[slot], d4 = B.rayD[slot];
-    o = v3(o4.x, o4.y, o4.z); d = v3(d4.x, d4.y, d4.z);
+    float4 d4 = B.rayD[slot];
+    if (eye) {
+      o = v3(eye);
+    } else {
+      float4 o4 = B.rayO[slot];
+      o = v3(o4.x, o4.y, o4.z);
+    }
+    d = v3(d4.x, d4.y, d4.z);
     mode = TRAV_CLOSEST; bulbDist = 0.0f;
     return slot;
   }
@@ -231,7 +239,7 @@ __global__ RT_TRAV_ATTR void k_extend(DevScene S, PathBuf B, const uint32_t *que
 
   __shared__ uint32_t ldsPool[(kBlock / 64) * kPoolFields * kPoolSlots];
   TravCounters tc{};
-  ExtendSource src{B, queue, &B.counts->nActive};
+  ExtendSource src{B, queue, &B.counts->nActive, (bounce == 0 && S.cameraMode != 2) ? S.eye : nullptr};
   traverseQueue<ExtendSource, false, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[(bounce & 1) * 2].seg[0].next, ldsStack, ldsPool, tc);
   flushCounters<COUNT>(B.counts, tc, 0);
 }
@@ -279,7 +287,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
     slot = queue[i];
     // Loads that depend only on the path slot, then loads that depend only on the object, each group issued together:
     // the kernel is bound by the latency of these scattered reads, so they must not wait for one another.
-    float4 o4 = B.rayO[slot], d4 = B.rayD[slot];
+    const float4 d4 = B.rayD[slot];
+    // camera rays of a camera without a lens start at the eye, which k_raygen does not store per ray (bounce is uniform)
+    const float4 o4 = (bounce == 0 && S.cameraMode != 2) ? make_float4(S.eye[0], S.eye[1], S.eye[2], 0) : B.rayO[slot];
     int32_t prim = B.hitPrim[slot];
     float t = B.hitT[slot];
     // the path's random stream is a function of its pixel and sample index; only the draw count is stored
@@ -526,7 +536,7 @@ __global__ RT_TRAV_ATTR void k_shadow_then_extend(DevScene S, PathBuf B, const u
   }
   {
     TravCounters tc{};
-    ExtendSource src{B, queueNext, &B.counts->nNext};
+    ExtendSource src{B, queueNext, &B.counts->nNext, nullptr};
     // the next bounce's ticket counters: those of this bounce's rays have not been reset yet
     traverseQueue<ExtendSource, false, COUNT, kStackLds, kBlock>(S, src, &B.counts->ticket[((bounce + 1) & 1) * 2].seg[0].next, ldsStack, ldsPool, tc);
     flushCounters<COUNT>(B.counts, tc, 0);

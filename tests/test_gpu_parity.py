@@ -572,6 +572,28 @@ def test_light_contributions_that_are_implied_not_stored(lights):
         assert st.raysSkipped > 0 and st.raysPlaneAnswered > 0  # both implied kinds occur
 
 
+def test_point_light_behind_flat_boxes():
+    """A scene the random-scene tool found (tools/fuzz_parity.py --seed 39, scene 10746; kept as arrays in
+    tests/golden/fuzz_point_light_flat_boxes.npz): a mesh on a quarter-unit grid (flat, axis-aligned boxes) around a
+    point light. A visibility ray almost parallel to such a box gets a box entry distance that is several percent off
+    (the rounding of box - origin, times a huge reciprocal), so boxes must not be culled against the distance of the
+    bulb: the reference does not (src/acceleration/BVH.cpp:302-305 culls against the closest hit only), and a library
+    that did lit 79 pixels the reference leaves in shadow."""
+    from tests.desc_fixture import DescFromArrays
+    sc = DescFromArrays(np.load(os.path.join(REPO, "tests", "golden", "fuzz_point_light_flat_boxes.npz")))
+    dev, orc = capi.device_scene(sc.desc), oracle_scene(sc.desc)
+    o = sc.desc.contents.options
+    for bounces in (1, o.maxBounces):
+        opt = capi.RtOptions(o.width, o.height, o.bias, o.exposure, bounces, o.numRays, o.fisheye, o.focus, o.lens)
+        dev.set_view(options=opt); orc.set_view(options=opt)
+        img, st = dev.render(seed=10746)
+        ref, ost = orc.render(seed=10746)
+        assert np.array_equal(img[..., 3], ref[..., 3])
+        off = int((np.abs(img[..., :3] - ref[..., :3]).max(-1) > 1e-3).sum())
+        assert off <= 2, f"{off} pixels differ at maxBounces {bounces}"
+        assert st.raysClosest + st.raysAny + st.raysSkipped == ost.raysClosest + ost.raysAny
+
+
 def test_hip_library_rejects_what_it_cannot_do(scenes):
     _, dev, _ = scenes("config1")
     with pytest.raises(RuntimeError, match="RT_RNG_COUNTER"):
