@@ -82,6 +82,63 @@ def random_rays(rng, n):
     return o.astype(np.float32), d.astype(np.float32)
 
 
+def flat_box_scene(rng, k):
+    """Meshes whose vertices lie on a quarter-unit grid, most triangles flat in an axis-aligned plane (their leaves have
+    boxes of zero thickness), around point lights that sit a hair off a grid plane and closer than one unit to the
+    geometry: visibility rays from a flat triangle toward such a bulb run almost parallel to the flat boxes of its
+    neighbours, where the slab test's entry distance is worst conditioned (a huge reciprocal times a rounded difference),
+    and their un-normalised direction is shorter than 1, where the reference's box culling is over-aggressive
+    (src/acceleration/BVH.cpp:302-305 compares a distance in units of |d| with t in units of 1)."""
+    w, h = int(rng.integers(12, 65)), int(rng.integers(12, 65))
+    hs = capi.HostScene.new(w, h)
+    mats = [hs.add_material(capi.RT_MAT_DEFAULT),
+            hs.add_material(capi.RT_MAT_PLASTIC, Kd=0.7, Kr=0.3, eta=1.5, roughness=0.2),
+            hs.add_material(capi.RT_MAT_MIRROR, Kr=0.9, eta=1.5)]
+    ntri = int(rng.choice([40, 300, 1500, 4000]))
+    cell = float(rng.choice([0.25, 0.25, 0.5, 0.125]))
+    ext = int(rng.choice([3, 6, 10]))
+    base = rng.integers(-ext, ext + 1, size=(ntri, 1, 3)).astype(float)
+    tri = base + rng.integers(-2, 3, size=(ntri, 3, 3))
+    flat_axis = rng.integers(0, 3, size=ntri)
+    is_flat = rng.random(ntri) < 0.8
+    for a in range(3):  # flat in one axis: the three vertices share that coordinate
+        sel = is_flat & (flat_axis == a)
+        tri[sel, :, a] = base[sel, 0, a][:, None]
+    tri *= cell
+    v = tri.reshape(-1, 3)
+    f = np.arange(ntri * 3).reshape(ntri, 3)
+    center = np.array([0.0, 0.0, -3.0])
+    hs.add_mesh(v, rng.normal(size=v.shape), f, center=tuple(center), scale=float(rng.choice([1.0, 1.0, 2.0])),
+                color=tuple(rng.uniform(0.2, 1, size=3)) + (1.0,), material=int(rng.choice(mats)))
+    for _ in range(int(rng.choice([0, 0, 2, 8]))):
+        hs.add_sphere(tuple(rng.normal(size=3) + center), float(rng.uniform(0.05, 0.6)),
+                      color=tuple(rng.uniform(0, 1, size=3)) + (1.0,), material=int(rng.choice(mats)))
+    if rng.random() < 0.4:
+        n = np.zeros(3); n[int(rng.integers(0, 3))] = float(rng.choice([-1.0, 1.0]))
+        hs.add_plane(tuple(n), float(rng.uniform(1, 4)), color=tuple(rng.uniform(0, 1, size=3)) + (1.0,), material=mats[0])
+    for _ in range(int(rng.integers(1, 4))):
+        # a bulb inside the mesh, a hair off a grid plane in one or two axes
+        g = rng.integers(-ext, ext + 1, size=3).astype(float) * cell * 0.5
+        off = rng.choice([0.0, 1e-6, 1e-4, 3e-3, 0.02], size=3) * rng.choice([-1.0, 1.0], size=3)
+        hs.add_light(capi.RT_LIGHT_POINT, color=tuple(rng.uniform(1, 6, size=3)) + (1.0,), v=tuple(g + off + center))
+    if rng.random() < 0.3:
+        hs.add_light(capi.RT_LIGHT_DISTANT, color=tuple(rng.uniform(0, 1, size=3)) + (1.0,), v=tuple(np.round(rng.normal(size=3) * 2) / 2 + [0, 1e-3, 0]))
+    hs.set_camera(eye=tuple(rng.normal(size=3) * 0.3), forward=tuple(rng.normal(size=3) * 0.2 + np.array([0, 0, -1])), up=(0, 1, 0))
+    hs.set_options(w, h, maxBounces=int(rng.integers(1, 5)), numRays=int(rng.integers(1, 4)))
+    return hs.build()
+
+
+def near_parallel_rays(rng, n, cell=0.25):
+    """Rays that start on (or a hair off) grid planes and run almost parallel to them, many of them shorter than 1."""
+    o = np.round((rng.normal(size=(n, 3)) * 1.5) / cell) * cell + np.array([0, 0, -3])
+    o += rng.choice([0.0, 1e-4, -1e-4, 1e-6], size=(n, 3))
+    d = rng.normal(size=(n, 3))
+    ax = rng.integers(0, 3, size=n)
+    d[np.arange(n), ax] *= rng.choice([0.0, 1e-7, 1e-5, 1e-3], size=n)
+    d *= np.exp(rng.normal(size=(n, 1)) * 1.5 - 1.0)
+    return o.astype(np.float32), d.astype(np.float32)
+
+
 def same_bits(a, b):
     """Bit-equal, except that any NaN equals any NaN: x86 and gfx950 give NaNs of different sign and payload (a
     zero-length shading normal divided by its length, for instance)."""
@@ -121,6 +178,37 @@ def detail(hs, dev, orc, o, d):
         print(f"maxBounces {mb}: {ys.size} pixels differ by > 1e-6 (max {diff.max():.3g}), rays gpu {st.raysClosest + st.raysAny + st.raysSkipped} cpu {ost.raysClosest + ost.raysAny}")
         for y, x in list(zip(ys, xs))[:6]:
             print(f"   pixel ({x},{y}): gpu {img[y, x].tolist()} cpu {ref[y, x].tolist()}")
+
+
+def check_scene(hs, dev, orc, o, d, frame_seed):
+    """One scene on the HIP library and on the CPU restatement: rays (o, d) as closest and as any-hit queries, the primary
+    rays, and the scene's frame. Returns {"ok", "same_counts", "rays", "what"}: ok = every query bit-equal (ids, bits of
+    t, point, normal; visibility answers), alpha equal, at most 1 % of the pixels (or 2) off by more than 1e-3."""
+    g, r = dev.trace_closest(o, d), orc.trace_closest(o, d)
+    ok = all(same_bits(a, b) for a, b in zip(g, r))
+    ok = ok and np.array_equal(dev.trace_any(o, d), orc.trace_any(o, d))
+    gi, gt = dev.trace_primary(); oi, ot = orc.trace_primary()
+    ok = ok and np.array_equal(gi, oi) and same_bits(gt, ot)
+    img, st = dev.render(seed=frame_seed); ref, ost = orc.render(seed=frame_seed)
+    finite = np.isfinite(ref).all() and np.isfinite(img).all()
+    mse = float(((img[..., :3] - ref[..., :3]) ** 2).mean()) if finite else 0.0
+    psnr = 200.0 if mse == 0 else 10 * np.log10(1.0 / mse)
+    same_counts = st.raysClosest + st.raysAny + st.raysSkipped == ost.raysClosest + ost.raysAny
+    # A last-bit difference between the device's and glibc's sinf / cosf / acosf can send ONE path of a frame the other
+    # way at a branch (lobe choice, Fresnel test): a handful of rays more or less and a few pixels off. That is
+    # counted apart ("diverged"); a mismatch is anything more: queries not bit-equal, alpha differing, or more
+    # than 1 % of the pixels off.
+    npx = img.shape[0] * img.shape[1]
+    off = int((np.abs(img[..., :3] - ref[..., :3]).max(-1) > 1e-3).sum()) if finite else npx
+    alpha_ok = bool(np.array_equal(img[..., 3], ref[..., 3]))
+    ok_img = alpha_ok and off <= max(2, npx // 100)
+    d_ = hs.desc.contents
+    o_ = d_.options
+    what = (f"prims {d_.numPrims} planes {d_.numPlanes} lights {d_.numLights} queries_ok {ok} alpha_ok {alpha_ok} psnr {psnr:.1f} "
+            f"counts {same_counts} | {o_.width}x{o_.height} spp {o_.numRays} bounces {o_.maxBounces} pixels>1e-3: {off} rays gpu "
+            f"{st.raysClosest + st.raysAny + st.raysSkipped} cpu {ost.raysClosest + ost.raysAny}")
+    return {"ok": bool(ok and ok_img), "same_counts": bool(same_counts), "what": what, "off": off,
+            "rays": 2 * len(o) + gi.size + st.raysClosest + st.raysAny}
 
 
 def fuzz_device_bvh(args):
@@ -188,8 +276,9 @@ def main():
     t0 = time.time()
     k = bad = rays = diverged = 0
     while time.time() - t0 < args.seconds:
-        hs = random_scene(rng, k)
-        o, d = random_rays(rng, 20000)
+        flat = k % 5 == 4
+        hs = flat_box_scene(rng, k) if flat else random_scene(rng, k)
+        o, d = near_parallel_rays(rng, 20000) if flat else random_rays(rng, 20000)
         if args.only >= 0 and k < args.only:
             k += 1
             continue
@@ -197,34 +286,12 @@ def main():
         if args.only >= 0:
             detail(hs, dev, orc, o, d)
             return 0
-        g, r = dev.trace_closest(o, d), orc.trace_closest(o, d)
-        ok = all(same_bits(a, b) for a, b in zip(g, r))
-        ok = ok and np.array_equal(dev.trace_any(o, d), orc.trace_any(o, d))
-        gi, gt = dev.trace_primary(); oi, ot = orc.trace_primary()
-        ok = ok and np.array_equal(gi, oi) and same_bits(gt, ot)
-        img, st = dev.render(seed=k); ref, ost = orc.render(seed=k)
-        finite = np.isfinite(ref).all() and np.isfinite(img).all()
-        mse = float(((img[..., :3] - ref[..., :3]) ** 2).mean()) if finite else 0.0
-        psnr = 200.0 if mse == 0 else 10 * np.log10(1.0 / mse)
-        same_counts = st.raysClosest + st.raysAny + st.raysSkipped == ost.raysClosest + ost.raysAny
-        # A last-bit difference between the device's and glibc's sinf / cosf / acosf can send ONE path of a frame the other
-        # way at a branch (lobe choice, Fresnel test): a handful of rays more or less and a few pixels off. That is
-        # counted apart ("diverged"); a mismatch is anything more: queries not bit-equal, alpha differing, or more
-        # than 1 % of the pixels off.
-        npx = img.shape[0] * img.shape[1]
-        off = int((np.abs(img[..., :3] - ref[..., :3]).max(-1) > 1e-3).sum()) if finite else npx
-        ok_img = np.array_equal(img[..., 3], ref[..., 3]) and off <= max(2, npx // 100)
-        diverged += int(ok and ok_img and not same_counts)
-        rays += 2 * len(o) + gi.size + st.raysClosest + st.raysAny
-        if not (ok and ok_img):
+        res = check_scene(hs, dev, orc, o, d, k)
+        diverged += int(res["ok"] and not res["same_counts"])
+        rays += res["rays"]
+        if not res["ok"]:
             bad += 1
-            d_ = hs.desc.contents
-            o_ = d_.options
-            nbad = int((np.abs(img[..., :3] - ref[..., :3]).max(-1) > 1e-3).sum()) if finite else -1
-            print(f"MISMATCH scene {k}: prims {d_.numPrims} planes {d_.numPlanes} lights {d_.numLights} queries_ok {ok} "
-                  f"alpha_ok {np.array_equal(img[..., 3], ref[..., 3])} psnr {psnr:.1f} counts {same_counts} | {o_.width}x{o_.height} "
-                  f"spp {o_.numRays} bounces {o_.maxBounces} mode {k % 4} pixels>1e-3: {nbad} rays gpu "
-                  f"{st.raysClosest + st.raysAny + st.raysSkipped} cpu {ost.raysClosest + ost.raysAny}", flush=True)
+            print(f"MISMATCH scene {k}: {res['what']}", flush=True)
         dev.close(); orc.close()
         k += 1
         if k % 500 == 0:
