@@ -145,12 +145,25 @@ def main():
         if world > 1:
             dist.barrier()
 
-    from raytracer_amd import capi, multi_gpu
+    from raytracer_amd import capi, desc_io, multi_gpu
 
+    # The scene is parsed and its BVH built ONCE per host, by rank 0 with all host threads; the other ranks map the
+    # finished arrays (what rt_scene_create reads) instead of repeating the work on the same cores.
     t_setup = time.time()
     path = scene_files(args, rank, barrier)
-    hs = capi.HostScene.load(path).build()
-    desc = hs.desc
+    shared = os.path.join(os.path.dirname(path), f"flattened_w{world}")
+    t_build = 0.0
+    if rank == 0:
+        t = time.time()
+        hs = capi.HostScene.load(path).build()
+        t_build = time.time() - t
+        desc = hs.desc
+        if world > 1:
+            desc_io.save_desc(desc, shared)
+    barrier()
+    if rank != 0:
+        hs = desc_io.load_desc(shared)
+        desc = hs.desc
     d = desc.contents
     dev = capi.device_scene(desc, device=gpu)
     W, H = d.options.width, d.options.height
@@ -160,12 +173,19 @@ def main():
 
     gatherer = multi_gpu.TileGather(W, H, (args.tile, args.tile), rank, world, out.device)
 
+    gather_s = []  # per timed frame: this rank's time inside the gather (the render call before it has synchronised)
+
     def step():
-        return multi_gpu.render_frame(dev, out, rank, world, gatherer=gatherer, tile=(args.tile, args.tile), seed=56,
-                                      samples_per_pass=args.spp_pass)
+        st = multi_gpu.render_partition(dev, out, rank, world, tile=(args.tile, args.tile), seed=56, samples_per_pass=args.spp_pass)
+        if world > 1:
+            t = time.perf_counter()
+            gatherer.gather(out)
+            gather_s.append(time.perf_counter() - t)
+        return st
 
     for _ in range(args.warmup):
         step()
+    gather_s.clear()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -180,22 +200,40 @@ def main():
     rays_local = sum(s.raysClosest + s.raysAny + s.raysPlaneAnswered for s in stats)
     traversed_local = sum(s.raysClosest + s.raysAny for s in stats)
     samples_local = sum(s.cameraSamples for s in stats)
-    agg = torch.tensor([float(elapsed), float(rays_local), float(samples_local), float(traversed_local)], dtype=torch.float64, device=tdev)
+    skipped_local = sum(s.raysSkipped for s in stats)
+    plane_local = sum(s.raysPlaneAnswered for s in stats)
+    agg = torch.tensor([float(elapsed), float(rays_local), float(samples_local), float(traversed_local), float(skipped_local),
+                        float(plane_local)], dtype=torch.float64, device=tdev)
+    per_rank = None  # N > 1: what every rank measured, so that a slow run can be read rank by rank
     if world > 1:
         tmax = agg[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         sums = agg[1:].clone()
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        elapsed_local = elapsed
         elapsed, rays_total, samples_total, traversed_total = float(tmax[0]), float(sums[0]), float(sums[1]), float(sums[2])
+        skipped_total, plane_total = float(sums[3]), float(sums[4])
+        keys = ("msTotal", "msExtend", "msShade", "msShadow", "msDirect")
+        mine = torch.tensor([elapsed_local / args.steps * 1e3, sum(gather_s) / max(1, len(gather_s)) * 1e3, max(gather_s, default=0.0) * 1e3]
+                            + [sum(getattr(s, k) for s in stats) / args.steps for k in keys], dtype=torch.float64, device=tdev)
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        table = torch.stack(everyone).cpu().numpy()  # [rank, column]
+        cols = ("wall_ms_per_step", "gather_ms", "gather_ms_max") + keys
+        per_rank = {c: [round(float(v), 3) for v in table[:, i]] for i, c in enumerate(cols)}
     else:
         rays_total, samples_total, traversed_total = float(rays_local), float(samples_local), float(traversed_local)
+        skipped_total, plane_total = float(skipped_local), float(plane_local)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
     ms_per_step = elapsed / args.steps * 1e3
-    mrays = rays_total / elapsed / 1e6
+    # `value`: BVH traversal queries per second, one per BVH::findClosestObject call of the reference that this library also
+    # answers by walking the tree (src/acceleration/BVH.cpp:283). Queries a plane settles before the tree is needed and
+    # queries whose answer cannot matter are reported beside it, not in it.
+    mrays = traversed_total / elapsed / 1e6
 
     # ---- roofline of the dominant kernel: per-ray work counted by the kernels themselves on a few samples per pixel,
     # kernel time from the HIP events the library records around each launch of the timed steps.
@@ -221,11 +259,11 @@ def main():
         kname, kb, kms, krays, klaunch = "k_extend", b_ext, ms_ext, rays_ext, launches_ext
     else:
         kname, kb, kms, krays, klaunch = "k_shadow", b_sh, ms_sh, rays_sh, launches_sh
-    # What binds the traversal kernels is measured, not assumed: the hardware counters of this same command
-    # (tools/profile_on_box.sh -> tools/pmc_traffic.py -> profiles/pmc_traffic.json; counters cannot be read from inside
-    # this process) say how busy the vector ALUs, the L1 caches and the memory side are. They are reported only for the
-    # profiled workload and only while the kernel sources still hash to what was profiled; kernel time and the
-    # per-ray work are measured live, here.
+    # Live in this process: kernel time (HIP events the library records on its own stream around every launch of the timed
+    # steps) and the per-ray work (counted by the kernels on a few samples per pixel). Hardware counters cannot be read
+    # from inside the process: they come from the rocprofv3 passes of this same command (tools/profile_on_box.sh ->
+    # tools/pmc_traffic.py -> profiles/pmc_traffic.json) and are replayed only for the profiled workload and only while
+    # the kernel sources still hash to what was profiled.
     from tools import pmc_traffic
     prof = None
     tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
@@ -241,49 +279,48 @@ def main():
     lu_i, lu_p = ((cst.laneUseInnerExtend, cst.laneUsePrimExtend) if kname == "k_extend" else (cst.laneUseInnerShadow, cst.laneUsePrimShadow))
     lane_use = (inner + prims) / (inner / lu_i + prims / lu_p) if lu_i > 0 and lu_p > 0 else None
     avg_ms = kms / max(1, klaunch)
-    # Roofs measured on this GPU with tools/micro/l1_access_probe.hip (profiles/r02_micro_probes.txt): scattered 16-byte
-    # accesses that all hit the L1, and scattered 64-byte records served by the L2 / by the Infinity Cache.
-    L1_PEAK = 1.46          # L1 accesses per clock per CU
-    L2_RECORDS_PER_S = 209e9
-    IC_RECORDS_PER_S = 58e9
+    rays_per_launch = krays / max(1, klaunch)
+    alg_bytes = rays_per_launch * kb                      # algorithmic bytes of one launch
+    alg_gbs = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    L1_PEAK = 1.46  # L1 accesses per clock per CU with every access a hit: tools/micro/l1_access_probe.hip, profiles/r02_micro_probes.txt
     l1 = prof.get("l1_access_busy") if prof else None
-    mem_model = None
-    if prof and "l2_read_requests_per_launch" in prof and "l2_misses_per_launch" in prof:
-        # time the L1 misses of one launch would take at the probe's rates: hits in L2 + fetches from beyond it
-        t_min = ((prof["l2_read_requests_per_launch"] - prof["l2_misses_per_launch"]) / L2_RECORDS_PER_S
-                 + prof["l2_misses_per_launch"] / IC_RECORDS_PER_S)
-        mem_model = {"l2_read_requests_per_launch": prof["l2_read_requests_per_launch"], "l2_misses_per_launch": prof["l2_misses_per_launch"],
-                     "l2_hit": prof.get("l2_hit"), "time_at_probe_rates_ms": round(t_min * 1e3, 2),
-                     "frac": round(t_min / (prof["trace_avg_us"] * 1e-6), 4),
-                     "unit": "launch time the L1 misses alone would need at the measured scattered-record rates of L2 (209 G/s) and "
-                             "Infinity Cache (58 G/s), over the launch time"}
+    hbm_gbs = prof["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 if prof and avg_ms > 0 else None
     roofline = {
-        # The traversal kernels gather one 64-byte node or 48-byte object record per lane and step, every lane elsewhere. What
-        # they saturate is the rate at which a CU's vector L1 / texture addresser takes scattered lane accesses: adding one
-        # load per node step slows them by 12-28 %, adding 40 ALU instructions per step by 5 % (profiles/README.md).
-        "bound": "l1_scattered_access", "kernel": kname,
-        "unit": "L1 accesses per clock per CU (TCP_TOTAL_CACHE_ACCESSES_sum / 256 CUs / GPU cycles), one per lane and load instruction",
-        "peak": L1_PEAK, "achieved": l1, "frac": round(l1 / L1_PEAK, 4) if l1 else None,
-        "ta_busy": prof.get("ta_busy") if prof else None,
+        "kernel": kname,
+        # Algorithmic bytes (32 B ray + 64 B per node visit + 48 B per object test + 16 B hit) per launch over the
+        # launch's duration, against the HBM peak. The traversal kernels re-read the upper tree from the L1 / L2 caches, so
+        # this exceeds the HBM peak: it is cache traffic. What actually leaves the L2 is `traffic` (hardware counters).
+        "bound": "latency (dependent scattered record fetches, 7 waves/SIMD)",
+        "achieved": round(alg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / HBM_PEAK_GBS, 4),
+        "algorithmic_vs_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 4), "served_by": "L1/L2",
+        "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_ray": round(kb, 1), "rays_per_launch": round(rays_per_launch, 1),
+        "avg_launch_ms": round(avg_ms, 4),
+        "traffic": prof["hbm_bytes_per_launch"] if prof else None,
+        "hbm_measured": ({"achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
+                          "traffic_over_algorithmic": round(prof["hbm_bytes_per_launch"] / alg_bytes, 4) if alg_bytes else None,
+                          "counters": "FETCH_SIZE (as counted: scattered 64-byte reads are counted exactly, profiles/r02_micro_probes.txt) + WRITE_SIZE"}
+                         if prof else None),
+        # The hardware rate the kernel comes nearest to. It does NOT bind: fetching records by quads (3.8 accesses per clock)
+        # gains 0-9 % at equal occupancy, while time follows the number of resident waves and every extra dependent round
+        # trip per node step (experiment tables in DESIGN.md).
+        "nearest_roof": {"name": "L1 scattered-access rate", "achieved": l1, "peak": L1_PEAK,
+                         "unit": "L1 accesses per clock per CU (TCP_TOTAL_CACHE_ACCESSES_sum / 256 CUs / GPU cycles)",
+                         "frac": round(l1 / L1_PEAK, 4) if l1 else None, "binds": False,
+                         "peak_source": "this repository's micro-probe (tools/micro/l1_access_probe.hip), not a figure of the hardware guide",
+                         "ta_busy": prof.get("ta_busy") if prof else None},
         "lane_use": round(lane_use, 4) if lane_use else None,
         "lane_use_by_loop": {"extend_inner": round(cst.laneUseInnerExtend, 3), "extend_prim": round(cst.laneUsePrimExtend, 3),
                              "shadow_inner": round(cst.laneUseInnerShadow, 3), "shadow_prim": round(cst.laneUsePrimShadow, 3)},
         "valu": ({"busy": prof.get("valu_busy"), "unit": "SQ_ACTIVE_INST_VALU * 4 / 1024 SIMDs / GPU cycles",
-                  "instr_per_ray": round(prof["valu_instr_per_launch"] / (krays / max(1, klaunch)), 1) if "valu_instr_per_launch" in prof else None}
+                  "instr_per_ray": round(prof["valu_instr_per_launch"] / rays_per_launch, 1) if "valu_instr_per_launch" in prof else None}
                  if prof else None),
-        "l2_and_beyond": mem_model,
-        "hbm": ({"bound": "hbm", "achieved": round(prof["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": round(prof["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                 "traffic": prof["hbm_bytes_per_launch"], "traffic_unit": "bytes per launch leaving the L2 (FETCH_SIZE as counted for scattered "
-                 "64-byte records, see tools/pmc_traffic.py, + WRITE_SIZE)"} if prof else None),
-        "traffic": prof["hbm_bytes_per_launch"] if prof else None,
-        "profile": ({"file": "profiles/pmc_traffic.json", "avg_launch_ms": round(prof.get("trace_avg_us", 0) / 1e3, 4)}
-                    if prof else "no counters for this workload / these kernel sources: rerun tools/profile_on_box.sh"),
-        # what a cache-less machine would have to fetch: every node visit 64 B, every object test 48 B (served by L1/L2 here)
-        "algorithmic_cache_bytes_per_launch": int(krays * kb / max(1, klaunch)),
-        "algorithmic_cache_GBps": round((krays * kb) / (kms * 1e-3) / 1e9, 1) if kms > 0 else None,
-        "bytes_per_ray": round(kb, 1), "rays_per_launch": round(krays / max(1, klaunch), 1),
-        "avg_launch_ms": round(avg_ms, 4),
+        "l2": ({"read_requests_per_launch": prof.get("l2_read_requests_per_launch"), "misses_per_launch": prof.get("l2_misses_per_launch"),
+                "hit": prof.get("l2_hit")} if prof else None),
+        "live": ["avg_launch_ms", "rays_per_launch", "bytes_per_ray", "algorithmic_bytes_per_launch", "achieved", "frac", "lane_use",
+                 "lane_use_by_loop", "mrays_per_s_in_kernel", "other_kernel"],
+        "replayed_from": ({"file": "profiles/pmc_traffic.json", "fields": ["traffic", "hbm_measured", "nearest_roof.achieved", "nearest_roof.ta_busy", "valu", "l2"],
+                           "profiled_avg_launch_ms": round(prof.get("trace_avg_us", 0) / 1e3, 4), "source_sha1_matches": True}
+                          if prof else "no counters for this workload / these kernel sources: rerun tools/profile_on_box.sh"),
         "mrays_per_s_in_kernel": round(krays / (kms * 1e-3) / 1e6, 1) if kms > 0 else 0.0,
         "other_kernel": {"kernel": "k_shadow" if kname == "k_extend" else "k_extend",
                          "bytes_per_ray": round(b_sh if kname == "k_extend" else b_ext, 1),
@@ -335,23 +372,33 @@ def main():
                                   + ("RCCL gather to rank 0" if backend == "nccl" else f"REHEARSAL: {backend} gather, ranks share GPUs")},
         "wall_time_s": round(ms_per_step / 1e3, 3),
         "camera_msamples_per_s": round(samples_total / elapsed / 1e6, 2),
-        "value_definition": "queries answered by intersecting scene geometry per second: BVH-traversed + settled by a plane before "
-                            "the BVH; zero-contribution queries the reference also traces are excluded",
+        "value_definition": "BVH traversal queries per second (camera, bounce and visibility rays that walked the tree: one "
+                            "BVH::findClosestObject call of the reference each); queries a plane settles before the tree is needed and "
+                            "zero-contribution queries are counted apart",
         "mrays_bvh_traversed_per_s": round(traversed_total / elapsed / 1e6, 2),
-        "rays_per_frame": int(rays_total / args.steps),
+        # the same frame by two wider definitions of a ray
+        "mrays_geometry_answered_per_s": round(rays_total / elapsed / 1e6, 2),   # + visibility queries one of the scene's planes settles
+        "mrays_reference_equivalent_per_s": round((traversed_total + skipped_total) / elapsed / 1e6, 2),  # every query the reference traces for this frame
         "rays_bvh_traversed_per_frame": int(traversed_total / args.steps),
-        # visibility queries the reference traces and this library answers without a BVH traversal: zero contribution
-        # (not part of `value`), or a plane alone decides (part of `value`, see value_definition)
-        "rays_skipped_per_frame": int(sum(s.raysSkipped for s in stats) / args.steps),
-        "rays_plane_answered_per_frame": int(sum(s.raysPlaneAnswered for s in stats) / args.steps),
-        "reference_queries_per_frame": int((traversed_total + sum(s.raysSkipped for s in stats)) / args.steps) if world == 1 else None,
-        "rays_per_camera_sample": round(rays_total / max(1.0, samples_total), 3),
+        "rays_plane_answered_per_frame": int(plane_total / args.steps),
+        # visibility queries the reference traces and this library answers without a BVH traversal (zero contribution, or a plane alone decides)
+        "rays_not_traversed_per_frame": int(skipped_total / args.steps),
+        "reference_queries_per_frame": int((traversed_total + skipped_total) / args.steps),
+        "rays_per_camera_sample": round(traversed_total / max(1.0, samples_total), 3),
         "kernel_ms_per_frame": {k: round(sum(getattr(s, k) for s in stats) / args.steps, 2)
                                 for k in ("msTotal", "msRaygen", "msExtend", "msShade", "msShadow", "msDirect", "msAccumulate", "msResolve")},
-        "setup_s": round(setup_s, 1),
+        "setup_s": round(setup_s, 1), "scene_build_s": round(t_build, 2),
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
+    if world > 1:
+        # one line per rank would be easier to read and harder to parse: lists are indexed by rank
+        line["multi_gpu"] = {"backend": backend, "world_size": dist.get_world_size(),
+                             "gather_ms": round(sum(gather_s) / max(1, len(gather_s)) * 1e3, 3),   # rank 0, per frame
+                             "gather_ms_max_over_ranks": max(per_rank["gather_ms_max"]),
+                             "gather_bytes_per_rank": int(W * H * 16 / world),
+                             "per_rank": per_rank,
+                             "scene": "parsed and BVH built once, by rank 0; other ranks map the flattened arrays"}
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -211,13 +211,15 @@ int rt_scene_set_view(RtScene *scene, const RtCamera *camera, const RtOptions *o
  * t[j] = IntersectionInfo::t (+inf on a miss). Row-major over the rectangle; host or device buffers. */
 int rt_trace_primary(RtScene *scene, int32_t x0, int32_t y0, int32_t w, int32_t h, int32_t *primId, float *t);
 
-/* rt_trace_primary for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc). It has no counterpart in the reference. Same arguments, same results bit for bit;
- * the queue ticket and the device-side staging of ids and t live in a static device array of the library (32 MiB + 1 KiB
- * per GPU, held from library load to process exit) instead of memory the scene allocates, and the call makes no
- * hipMalloc / hipFree. Limits: w * h <= rt_trace_primary_static_max_pixels() (4 Mi pixels; larger rectangles are
- * refused with RT_ERR_INVALID); all scenes on one GPU share that GPU's array, so calls that overlap in time on one GPU
- * race (calls on different GPUs do not). */
+/* rt_trace_primary for callers that cannot allocate device memory (tight serving loops, harnesses that forbid
+ * hipMalloc). It has no counterpart in the reference. Same arguments, same results bit for bit; the queue ticket and the
+ * device-side staging of ids and t live in a static device array of the library (32 MiB + 1 KiB per GPU, held from
+ * library load to process exit) instead of memory the scene allocates, and the call makes no hipMalloc / hipFree. Like
+ * rt_trace_primary it is synchronous and runs on the library's own stream (it returns once primId and t are written), so
+ * it is not something to record into a HIP graph. Limits: w * h <= rt_trace_primary_static_max_pixels() (4 Mi pixels;
+ * larger rectangles are refused with RT_ERR_INVALID); all scenes on one GPU share that GPU's array, so calls that
+ * overlap in time on one GPU race (calls on different GPUs do not). The array's device address is looked up on the
+ * first call on each GPU; a GPU on which that fails makes this entry point return RT_ERR_DEVICE and nothing else. */
 int rt_trace_primary_static(RtScene *scene, int32_t x0, int32_t y0, int32_t w, int32_t h, int32_t *primId, float *t);
 int64_t rt_trace_primary_static_max_pixels(void);
 

@@ -246,12 +246,18 @@ bool buildLbvh(hipStream_t stream, const float *aabbMin, const float *aabbMax, i
   hipError_t e;
   if ((e = hipMalloc(reinterpret_cast<void **>(&out->order), (size_t)n * sizeof(uint32_t))) != hipSuccess) return fail("hipMalloc", e);
 
-  hipEvent_t evA = nullptr, evB = nullptr;
-  (void)hipEventCreate(&evA); (void)hipEventCreate(&evB);
-  (void)hipEventRecord(evA, stream);
+  // the two timing events are destroyed on every way out of this function
+  struct Events {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  } ev;
+  if ((e = hipEventCreate(&ev.a)) != hipSuccess) return fail("hipEventCreate", e);
+  if ((e = hipEventCreate(&ev.b)) != hipSuccess) return fail("hipEventCreate", e);
+  if ((e = hipEventRecord(ev.a, stream)) != hipSuccess) return fail("hipEventRecord", e);
   k_init_bounds<<<1, 64, 0, stream>>>(bounds);
   k_centre_bounds<<<gridOf(n), kBuildBlock, 0, stream>>>(aabbMin, aabbMax, n, bounds);
   k_morton<<<gridOf(n), kBuildBlock, 0, stream>>>(aabbMin, aabbMax, n, bounds, keys, vals);
+  if ((e = hipGetLastError()) != hipSuccess) return fail("launch of the bounds / Morton-code kernels", e);
   {
     size_t tempBytes = 0;
     if ((e = rocprim::radix_sort_pairs(nullptr, tempBytes, keys, keysSorted, vals, out->order, (size_t)n, 0, kMortonBits, stream)) != hipSuccess)
@@ -261,13 +267,14 @@ bool buildLbvh(hipStream_t stream, const float *aabbMin, const float *aabbMax, i
     if ((e = rocprim::radix_sort_pairs(temp, tempBytes, keys, keysSorted, vals, out->order, (size_t)n, 0, kMortonBits, stream)) != hipSuccess)
       return fail("radix sort", e);
   }
-  (void)hipMemsetAsync(flags, 0, 2 * sizeof(uint32_t), stream);
+  if ((e = hipMemsetAsync(flags, 0, 2 * sizeof(uint32_t), stream)) != hipSuccess) return fail("hipMemsetAsync", e);
   Box rootBox{};
   if (numInternal > 0) {
-    (void)hipMemsetAsync(arrived, 0, (size_t)numInternal * sizeof(uint32_t), stream);
+    if ((e = hipMemsetAsync(arrived, 0, (size_t)numInternal * sizeof(uint32_t), stream)) != hipSuccess) return fail("hipMemsetAsync", e);
     k_radix_tree<<<gridOf(numInternal), kBuildBlock, 0, stream>>>(keysSorted, n, left, right, first, last, parentOfNode, parentOfLeaf);
     k_fit_boxes<<<gridOf(n), kBuildBlock, 0, stream>>>(aabbMin, aabbMax, out->order, n, left, right, parentOfNode, parentOfLeaf, arrived, nodeBox);
     k_mark_records<<<gridOf(numInternal), kBuildBlock, 0, stream>>>(first, last, numInternal, isRecord);
+    if ((e = hipGetLastError()) != hipSuccess) return fail("launch of the tree / box kernels", e);
     size_t tempBytes = 0;
     if ((e = rocprim::exclusive_scan(nullptr, tempBytes, isRecord, recordIndex, 0u, (size_t)numInternal, rocprim::plus<uint32_t>(), stream)) != hipSuccess)
       return fail("scan (size query)", e);
@@ -295,15 +302,15 @@ bool buildLbvh(hipStream_t stream, const float *aabbMin, const float *aabbMax, i
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail("copy", e);
     std::memcpy(rootBox.mn, mn, 12); std::memcpy(rootBox.mx, mx, 12);
   }
-  (void)hipEventRecord(evB, stream);
+  if ((e = hipGetLastError()) != hipSuccess) return fail("launch of the record kernel", e);
+  if ((e = hipEventRecord(ev.b, stream)) != hipSuccess) return fail("hipEventRecord", e);
   uint32_t hostFlags[2] = {0, 0};
   if ((e = hipMemcpyAsync(hostFlags, flags, sizeof hostFlags, hipMemcpyDeviceToHost, stream)) != hipSuccess) return fail("copy", e);
   if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail("build kernels", e);
   out->boxesFinite = hostFlags[0] == 0u;
   for (int k = 0; k < 3; ++k) out->boxesFinite = out->boxesFinite && std::isfinite(rootBox.mn[k]) && std::isfinite(rootBox.mx[k]);
   if ((e = hipGetLastError()) != hipSuccess) return fail("kernel launch", e);
-  (void)hipEventElapsedTime(&out->buildMs, evA, evB);
-  (void)hipEventDestroy(evA); (void)hipEventDestroy(evB);
+  if (hipEventElapsedTime(&out->buildMs, ev.a, ev.b) != hipSuccess) out->buildMs = 0.0f;
   std::memcpy(out->rootMin, rootBox.mn, 12);
   std::memcpy(out->rootMax, rootBox.mx, 12);
   return true;

@@ -1368,7 +1368,8 @@ inline unsigned persistentGrid(const RtScene *s, int64_t n) {
 // rt_trace_primary_static keeps everything it needs beyond the caller's buffers (the queue ticket and the device-side
 // staging of ids and t) in this array, which is part of the code object: every GPU the library runs on holds its own
 // copy at its own address from the moment the code object is loaded until the process ends. Host code never uses the
-// array's name as an address; it asks the runtime for the device address once per device (resolveStaticScratch).
+// array's name as an address; it asks the runtime for the device address once per device (resolveStaticScratch, at the
+// first rt_trace_primary_static on that device).
 constexpr int64_t kStaticTraceMaxPixels = (int64_t)1 << 22;  // 4 Mi pixels (2048 x 2048): 32 MiB of staging
 constexpr size_t kStaticTicketBytes = sizeof(Ticket) * kQueueSegments;  // 1 KiB
 constexpr size_t kStaticScratchBytes = kStaticTicketBytes + (size_t)kStaticTraceMaxPixels * 8;
@@ -1418,10 +1419,6 @@ RtScene *rt_scene_create(const RtSceneDesc *desc, int device) try {
     if (const char *x = std::getenv("RT_TRAV_EXTRA_LDS")) s->extraLds = (size_t)std::max(0L, std::atol(x));
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_shadow<false>, kBlock, s->extraLds) == hipSuccess && nb > 0) s->blocksPerCU = nb;
     if (const char *x = std::getenv("RT_TRAV_BLOCKS_PER_CU")) s->blocksPerCU = std::max(1, std::atoi(x));
-  }
-  if ((e = resolveStaticScratch(device)) != hipSuccess) {
-    g_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
-    return nullptr;
   }
   if ((e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)) != hipSuccess) {
     g_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
@@ -1602,8 +1599,10 @@ int rt_trace_primary_static(RtScene *s, int32_t x0, int32_t y0, int32_t w, int32
     return failMsg(RT_ERR_INVALID, "rt_trace_primary_static: " + std::to_string(n) + " pixels exceed the static scratch buffer's " +
                                        std::to_string(kStaticTraceMaxPixels) + "; use rt_trace_primary or a smaller rectangle");
   HIP_TRY(hipSetDevice(s->device));
-  char *base = static_cast<char *>(s->device < kMaxDevices ? g_scratchPtr[s->device] : nullptr);  // resolved by rt_scene_create
-  if (!base) return failMsg(RT_ERR_DEVICE, "the static scratch buffer has no address on this device");
+  // first call on this GPU: ask the runtime where this GPU's copy of the array lies (with that device current)
+  if (hipError_t e = resolveStaticScratch(s->device); e != hipSuccess)
+    return failMsg(RT_ERR_DEVICE, std::string("the static scratch buffer has no address on this device: hipGetSymbolAddress: ") + hipGetErrorString(e));
+  char *base = static_cast<char *>(g_scratchPtr[s->device]);
   uint32_t *ticket = reinterpret_cast<uint32_t *>(base);
   int32_t *dPrim = reinterpret_cast<int32_t *>(base + kStaticTicketBytes);
   float *dT = reinterpret_cast<float *>(base + kStaticTicketBytes + (size_t)kStaticTraceMaxPixels * 4);
@@ -1909,7 +1908,15 @@ int rt_framebuffer_gather(RtScene *dst, RtScene *const *srcs, int32_t numSrcs) t
   }
   HIP_TRY(hipSetDevice(dst->device));
   if ((int32_t)dst->peers.size() < numSrcs) dst->peers.resize(numSrcs);
+  // Copies and scatter kernels of the sources handled so far run on streams of their own and write dst->fb: whichever
+  // way this function is left, they have finished before the caller can read, re-render or destroy anything.
+  struct Drain {
+    std::vector<PeerSlot> &slots;
+    int32_t used = 0;
+    ~Drain() { for (int32_t k = 0; k < used; ++k) if (slots[k].stream) (void)hipStreamSynchronize(slots[k].stream); }
+  } drain{dst->peers};
   for (int32_t i = 0; i < numSrcs; ++i) {
+    drain.used = i + 1;
     RtScene *src = srcs[i];
     PeerSlot &slot = dst->peers[i];
     const int64_t npix = src->pixCount;

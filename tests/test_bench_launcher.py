@@ -53,3 +53,14 @@ def test_gpus_2_rehearsal_on_one_gpu_reports_two_ranks(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     line = _json_line(r.stdout)
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["width"] == 256
+    # `value` counts BVH traversal queries only; the wider definitions ride along
+    assert line["value"] == line["mrays_bvh_traversed_per_s"] <= line["mrays_geometry_answered_per_s"]
+    # what a slow multi-GPU run is read from: the gather's share and every rank's own times
+    mg = line["multi_gpu"]
+    assert mg["world_size"] == 2 and mg["backend"] == "gloo" and mg["gather_ms"] >= 0 and mg["gather_bytes_per_rank"] == 256 * 256 * 16 // 2
+    for key in ("wall_ms_per_step", "gather_ms", "msTotal", "msExtend", "msShadow", "msShade", "msDirect"):
+        assert len(mg["per_rank"][key]) == 2 and all(v >= 0 for v in mg["per_rank"][key]), key
+    # the scene was built once: rank 0 reports the build, the flattened arrays are on disk for the other rank
+    assert line["scene_build_s"] > 0 and os.path.exists(os.path.join(str(tmp_path), "flattened_w2", "desc.json"))
+    rl = line["roofline"]
+    assert rl["bound"].startswith("latency") and rl["served_by"] == "L1/L2" and "live" in rl and "replayed_from" in rl

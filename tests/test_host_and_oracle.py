@@ -481,3 +481,59 @@ def test_host_parallel_loops_cover_every_index_and_hand_exceptions_to_the_caller
                     "-Wl,-rpath," + libdir, "-o", exe], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+
+
+def test_flattened_scene_survives_the_trip_through_files(tmp_path, scene_path):
+    """raytracer_amd/desc_io.py: the arrays one process flattens are what another maps — same records, so the CPU
+    restatement renders the same frame and finds the same hits from either description (textures, texture coordinates
+    and planes included)."""
+    from raytracer_amd import desc_io
+    from tests.oracle_binding import oracle_scene
+    hs = capi.HostScene.load(scene_path("readme_small")).build()
+    desc_io.save_desc(hs.desc, str(tmp_path / "flat"))
+    back = desc_io.load_desc(str(tmp_path / "flat"))
+    a, b = hs.desc.contents, back.desc.contents
+    assert (a.numPrims, a.numNodes, a.numPlanes, a.numLights, a.numMaterials, a.numTextures) == \
+           (b.numPrims, b.numNodes, b.numPlanes, b.numLights, b.numMaterials, b.numTextures)
+    assert a.numTextures > 0 and bool(a.primTexCoords) == bool(b.primTexCoords)
+    one, two = oracle_scene(hs.desc, threads=2), oracle_scene(back.desc, threads=2)
+    ids1, t1 = one.trace_primary(); ids2, t2 = two.trace_primary()
+    assert np.array_equal(ids1, ids2) and np.array_equal(t1.view(np.uint32), t2.view(np.uint32))
+    f1, _ = one.render(seed=5); f2, _ = two.render(seed=5)
+    assert np.array_equal(np.asarray(f1).view(np.uint32), np.asarray(f2).view(np.uint32))
+    one.close(); two.close()
+
+
+def test_redchair_tree_is_buildable_and_consistent(golden):
+    """redchair.txt of the reference (fisheye, flat `trif` quads) as arrays: the reference's own BVH build dies on it
+    (src/acceleration/BVH.cpp:93-99, undefined bin index when a node's centroids coincide on an axis), so nothing pins the
+    tree; the host library's tree for it must at least be a tree over all objects whose boxes hold their children's, and
+    the CPU restatement must find, through it, exactly the hits a loop over all triangles finds for rays of unit length
+    or longer (for those the reference's culling is conservative)."""
+    from tests.desc_fixture import DescFromArrays
+    g = golden("bundled_redchair")
+    nodes = np.asarray(g["nodes"]).reshape(-1, 8)
+    boxes = nodes[:, :6].view(np.float32)
+    n = int(np.asarray(g["primKind"]).shape[0])
+    covered = np.zeros(n, bool)
+    for i, row in enumerate(nodes):
+        if row[7] > 0:
+            assert not covered[row[6]:row[6] + row[7]].any()
+            covered[row[6]:row[6] + row[7]] = True
+        else:
+            for c in (i + 1, int(row[6])):
+                assert np.all(boxes[c, :3] >= boxes[i, :3]) and np.all(boxes[c, 3:] <= boxes[i, 3:])
+    assert covered.all()
+    full = DescFromArrays(g, width=96, height=96)
+    orc = oracle_scene(full.desc, threads=4)
+    flat = DescFromArrays({**{k: g[k] for k in g.files}, "nodes": np.array([[0, 0, 0, 0, 0, 0, 0, n]], np.int32)}, width=96, height=96)
+    fn = np.asarray(flat._keep["nodes"]).view(np.float32)
+    fn[0, :3] = boxes[0, :3]; fn[0, 3:6] = boxes[0, 3:]
+    brute = oracle_scene(flat.desc, threads=4)  # one leaf holding every object: no box decides anything
+    rng = np.random.default_rng(3)
+    o = (rng.normal(size=(4000, 3)) * 2 + np.array([0, 1, -2])).astype(np.float32)
+    d = rng.normal(size=(4000, 3)).astype(np.float32)
+    d *= ((1.0 + rng.random((4000, 1))) / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)  # lengths 1 .. 2
+    a, b = orc.trace_closest(o, d), brute.trace_closest(o, d)
+    assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and (a[0] >= 0).sum() > 400
+    orc.close(); brute.close()

@@ -1,6 +1,8 @@
 """rt_trace_primary_static: the entry point that allocates nothing (its queue ticket and the device-side staging of
 ids and t live in a static device array of the library). Checked through the C ABI against rt_trace_primary, bit for
 bit, on two calls in a row, the second smaller than the first (the array keeps the first call's contents)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -41,6 +43,39 @@ def test_static_entry_matches_allocating_entry_twice_second_smaller(scene_path):
         assert _same((ids, t), (wi, wt))
     finally:
         dev.close()
+
+
+def _device_free_bytes():
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
+def test_static_entry_allocates_no_device_memory_on_a_fresh_scene(scene_path):
+    """The static entry is the FIRST thing called on a fresh scene, before any rt_trace_primary has given the scene its
+    own staging: if it fell back to the scene's grow-on-demand buffers, the GPU's free memory would drop. It must not move,
+    on the first call or on a second, smaller one. (A first scene warms the runtime: loading the code object, which is what
+    places the static array, and the runtime's own copy staging are not this entry point's doing.)"""
+    warm = capi.device_scene(capi.HostScene.load(scene_path("mesh1k")).build().desc)
+    warm.trace_primary_static()
+    hs = capi.HostScene.load(scene_path("mesh70k")).build()
+    dev = capi.device_scene(hs.desc)
+    try:
+        before = _device_free_bytes()
+        first = dev.trace_primary_static()
+        after_first = _device_free_bytes()
+        rect = dict(x0=100, y0=200, w=301, h=77)
+        second = dev.trace_primary_static(**rect)
+        after_second = _device_free_bytes()
+        assert before == after_first == after_second, (before, after_first, after_second)
+        # only now the allocating entry point, as the checker
+        want = dev.trace_primary()
+        assert after_second - _device_free_bytes() >= 2 * 1080 * 1080 * 4, "rt_trace_primary is expected to allocate its staging"
+        assert _same(first, want)
+        assert _same(second, (want[0][200:277, 100:401], want[1][200:277, 100:401]))
+    finally:
+        dev.close(); warm.close()
 
 
 def test_static_entry_on_a_second_scene_of_the_same_device(scene_path):

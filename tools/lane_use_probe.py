@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Lane-utilisation probe (GPU box): counters of the traversal kernels for maxBounces = 1..4 on the bench scene."""
+import hashlib
 import os
 import sys
 import time
@@ -18,10 +19,12 @@ dev = capi.device_scene(hs.desc)
 o = hs.desc.contents.options
 for mb in [int(x) for x in os.environ.get('PROBE_BOUNCES', '1,2,4').split(',')]:
     dev.set_view(options=capi.RtOptions(o.width, o.height, o.bias, o.exposure, mb, int(os.environ.get("PROBE_SPP", "64")), o.fisheye, o.focus, o.lens))
-    dev.render(download=False)
+    img, _ = dev.render()
+    sha = hashlib.sha1(img.tobytes()).hexdigest()[:12]  # variants of the kernels must leave the frame as it is
     _, st = dev.render(download=False)
     _, c = dev.render(download=False, collect_counters=True)
     print(f"maxBounces={mb}: extend {st.raysExtend / st.msExtend / 1e3:.0f} Mrays/s ({st.msExtend:.2f} ms), shadow "
           f"{st.raysShadow / st.msShadow / 1e3:.0f} Mrays/s ({st.msShadow:.2f} ms), shade {st.msShade:.2f} ms, direct {st.msDirect:.2f} ms, resolve {st.msResolve:.2f} ms, total {st.msTotal:.2f} ms | lane use extend inner "
           f"{c.laneUseInnerExtend:.3f} prim {c.laneUsePrimExtend:.3f}, shadow inner {c.laneUseInnerShadow:.3f} prim {c.laneUsePrimShadow:.3f} | "
-          f"inner/ray ext {c.innerExtend / c.raysExtend:.1f} sh {c.innerShadow / c.raysShadow:.1f}, prim/ray ext {c.primExtend / c.raysExtend:.1f} sh {c.primShadow / c.raysShadow:.1f}")
+          f"inner/ray ext {c.innerExtend / c.raysExtend:.1f} sh {c.innerShadow / c.raysShadow:.1f}, prim/ray ext {c.primExtend / c.raysExtend:.1f} sh {c.primShadow / c.raysShadow:.1f} | frame {sha}"
+          + (f" | continuing INNER steps {(c.planeTests - 3 * (c.raysExtend + c.raysShadow + c.raysPlaneAnswered)) / c.innerExpansions:.3f} of all" if os.environ.get("PROBE_CONT") else ""))

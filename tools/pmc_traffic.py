@@ -6,7 +6,7 @@
 Units and corrections:
   * FETCH_SIZE and WRITE_SIZE are in KiB. On gfx950 FETCH_SIZE counts a 128-byte memory-side read request of a wide
     coalesced stream as 64 bytes, and counts the scattered 64-byte record reads of the traversal kernels exactly
-    (tools/micro/fetch_size_probe.hip, profiles/r02_fetch_size_calibration.txt: ratio 1.000 for a random 64-byte gather,
+    (tools/micro/fetch_size_probe.hip, profiles/r02_micro_probes.txt: ratio 1.000 for a random 64-byte gather,
     0.500 for a 16-byte-per-lane stream). `hbm_bytes_per_launch` therefore doubles the read side only for the
     streaming kernels (STREAMING below); the traversal kernels use the counter as it is.
   * SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs, GRBM_GUI_ACTIVE cycles summed over the 8 XCDs:

@@ -7,6 +7,9 @@ import re
 import sqlite3
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools.pmc_traffic import STREAMING  # noqa: E402  kernels whose FETCH_SIZE needs the x2 of a coalesced stream
+
 
 def short(n, width):
     m = re.search(r"(k_\w+(?:<[\w, ]+>)?)", n)
@@ -45,7 +48,9 @@ def pmc_stats(db):
 
 
 def derived(root):
-    """Per kernel: duration, HBM GB/s (FETCH_SIZE doubled: gfx950 counts a 128-byte read request as 64 bytes), VALU
+    """Per kernel: duration, HBM GB/s (FETCH_SIZE doubled for the streaming kernels only: gfx950 counts a 128-byte read
+    request of a coalesced stream as 64 bytes and the scattered 64-byte reads of the traversal kernels exactly; the same
+    per-kernel factor as tools/pmc_traffic.py, so that both files give one number per kernel), VALU
     utilisation (SQ_ACTIVE_INST_VALU is in 4-cycle units, summed over 1024 SIMDs; GRBM_GUI_ACTIVE summed over 8 XCDs),
     how a wavefront's resident time splits, cache hit rates."""
     def load(tag, fn):
@@ -72,7 +77,9 @@ def derived(root):
     for k in sorted(tr, key=lambda k: -tr[k]["avg_ns"] * tr[k]["calls"]):
         us = tr[k]["avg_ns"] / 1e3
         f, w = fe.get(k, {}).get("FETCH_SIZE"), wr.get(k, {}).get("WRITE_SIZE")
-        gbs = (2 * f + w) * 1024 / (us * 1e-6) / 1e9 if f is not None and w is not None and us > 0 else None
+        kshort = re.sub(r"<.*", "", k)
+        factor = 2 if kshort in STREAMING else 1
+        gbs = (factor * f + w) * 1024 / (us * 1e-6) / 1e9 if f is not None and w is not None and us > 0 else None
         s_ = sq.get(k, {})
         valu = (s_["SQ_ACTIVE_INST_VALU"] * 4 / 1024) / (s_["GRBM_GUI_ACTIVE"] / 8) if "SQ_ACTIVE_INST_VALU" in s_ and s_.get("GRBM_GUI_ACTIVE") else None
         wc = s_.get("SQ_WAVE_CYCLES")
