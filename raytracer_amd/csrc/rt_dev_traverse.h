@@ -183,18 +183,6 @@ enum { TRAV_CLOSEST = 0, TRAV_ANY = 1, TRAV_POINT_LIGHT = 2, TRAV_SKIP = 3 };
 #ifndef RT_TAKE_MIN
 #define RT_TAKE_MIN 8
 #endif
-#ifndef RT_PRIM_PAIR
-#define RT_PRIM_PAIR 0
-#endif
-#ifndef RT_REFS_8B
-#define RT_REFS_8B 0
-#endif
-#ifndef RT_REFS_LATE
-#define RT_REFS_LATE 0
-#endif
-#ifndef RT_COUNT_CONT
-#define RT_COUNT_CONT 0
-#endif
 constexpr int kPoolSlots = RT_POOL_SLOTS;    // prepared queries a wavefront keeps in LDS (power of two)
 constexpr int kPoolFields = 13;   // dwords per prepared query
 constexpr int kPoolLow = RT_POOL_LOW;      // prepare more queries once at most this many are left
@@ -298,7 +286,7 @@ RT_DEV void innerStep(float4 a, float4 b, float4 c, int4 r, V3 o, V3 inv, float 
 }
 
 // One PRIM operation on the record (a, b, c) of object pi (expanded inside traverseQueue, where the lane state lives).
-#define RT_PRIM_STEP(a, b, c)                                                                                       \
+#define RT_PRIM_STEP()                                                                                              \
   do {                                                                                                              \
     bool accepted = intersectPrim(S, a, b, c, pi, o, nd, tBest, primBest);                                          \
     ++pi;                                                                                                           \
@@ -565,40 +553,15 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
     if (nInner >= nPrim) {
       // ---------------------------------------------------------------- INNER: both child boxes of the current node
       int n = nInner;
-#if RT_COUNT_CONT
-      bool cont = false;  // experiment: this lane's previous iteration of this loop descended into the node it is at now
-#endif
       do {
-#if RT_COUNT_CONT
-        if (COUNT && op == OP_INNER && cont) ++tc.planes;
-        cont = false;
-#endif
         if (op == OP_INNER) {
           if (COUNT) { ++tc.inner; tc.innerWaveIters += 1.0f / (float)n; }
           const float4 *N = reinterpret_cast<const float4 *>(nodeBase + ((uint32_t)cur << 6));
           a = N[0]; b = N[1]; c = N[2];
-#if RT_REFS_LATE
-          // the child references are read only once a child is known to be visited (a second, dependent read of a line the
-          // first three reads have just brought in): a step whose boxes are both missed or culled costs three accesses, not four
-          {
-            float tminL, tmaxL, tminR, tmaxR;
-            if (waveExact) { slabExact(o, inv, a.x, a.y, a.z, a.w, b.x, b.y, tminL, tmaxL); slabExact(o, inv, b.z, b.w, c.x, c.y, c.z, c.w, tminR, tmaxR); }
-            else { slabFinite(o, inv, a.x, a.y, a.z, a.w, b.x, b.y, tminL, tmaxL); slabFinite(o, inv, b.z, b.w, c.x, c.y, c.z, c.w, tminR, tmaxR); }
-            const bool any = (tmaxL >= tminL && tmaxL > 0 && tminL < tBest) || (tmaxR >= tminR && tmaxR > 0 && tminR < tBest);
-            r = make_int4(0, 0, 0, 0);
-            if (any) { const int2 r2 = reinterpret_cast<const int2 *>(N)[6]; r.x = r2.x; r.y = r2.y; }
-          }
-#elif RT_REFS_8B
-          { const int2 r2 = reinterpret_cast<const int2 *>(N)[6]; r.x = r2.x; r.y = r2.y; }
-#else
           r = reinterpret_cast<const int4 *>(N)[3];
-#endif
           const float lim = tBest;
           if (waveExact) innerStep<true, K, BLOCK>(a, b, c, r, o, inv, lim, stackCol, spill, sp, lo, cur, pi, pe, op);  // wave-uniform: valid for every ray, just slower
           else innerStep<false, K, BLOCK>(a, b, c, r, o, inv, lim, stackCol, spill, sp, lo, cur, pi, pe, op);
-#if RT_COUNT_CONT
-          cont = op == OP_INNER && (cur == r.x || cur == r.y);
-#endif
         }
         n = __popcll(__ballot(op == OP_INNER));
         if (canRefill && __popcll(__ballot(op >= OP_DONE)) >= kDoneBreak) break;
@@ -611,24 +574,8 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
         if (op == OP_PRIM) {
           if (COUNT) { ++tc.prims; tc.primWaveIters += 1.0f / (float)n; }
           const float4 *P = reinterpret_cast<const float4 *>(primBase + (uint32_t)pi * 48u);
-#if RT_PRIM_PAIR
-          // The objects of a leaf lie side by side and their addresses are known from the start: the records of this
-          // object and the next are fetched together, so that a leaf of n objects costs ceil(n / 2) fetch round trips.
-          // They are still tested one after the other, in array order, the second one only if the first left the lane in
-          // the leaf (src/acceleration/BVH.cpp:308-314: same tests, same order, same closest hit).
-          const bool two = pi + 1 < pe;
           a = P[0]; b = P[1]; c = P[2];
-          float4 a2 = a, b2 = b, c2 = c;
-          if (two) { a2 = P[3]; b2 = P[4]; c2 = P[5]; }
-          RT_PRIM_STEP(a, b, c);
-          if (two && op == OP_PRIM) {
-            if (COUNT) ++tc.prims;
-            RT_PRIM_STEP(a2, b2, c2);
-          }
-#else
-          a = P[0]; b = P[1]; c = P[2];
-          RT_PRIM_STEP(a, b, c);
-#endif
+          RT_PRIM_STEP();
         }
         n = __popcll(__ballot(op == OP_PRIM));
       } while (n > stayPrim);
