@@ -97,3 +97,44 @@ def test_tile_owner_matches_library_rule():
     assert own.shape == (50, 70)
     assert own[0, 0] == 0 and own[0, 32] == 1 and own[0, 64] == 2 and own[32, 0] == 0 and own[32, 32] == 1
     assert np.all(multi_gpu.tile_owner(9, 9, (4, 4), 1) == 0)
+
+
+def _shared_scene_worker(rank, world, port, scene_file, shared_dir, tile, result_path):
+    from raytracer_amd import desc_io
+    from tests.oracle_binding import oracle_scene
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # what bench.py does for N > 1: rank 0 parses the files and builds the BVH once, the others map the flattened arrays
+        if rank == 0:
+            hs = capi.HostScene.load(scene_file).build()
+            desc_io.save_desc(hs.desc, shared_dir)
+        dist.barrier()
+        if rank != 0:
+            hs = desc_io.load_desc(shared_dir)
+        o = hs.desc.contents.options
+        scene = oracle_scene(hs.desc, threads=2)
+        out = torch.zeros((o.height, o.width, 4), dtype=torch.float32)
+        multi_gpu.render_partition(scene, out, rank, world, tile=tile, seed=7)
+        multi_gpu.TileGather(o.width, o.height, tile, rank, world, out.device).gather(out)
+        if rank == 0:
+            np.save(result_path, out.numpy())
+        scene.close()
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_scene_built_once_and_mapped_by_the_other_ranks(tmp_path, scene_path):
+    """Three ranks, one scene build: the ranks that load the flattened arrays from files render the same pixels as ranks
+    that would have parsed the scene themselves (textured scene: texels and texture coordinates travel too)."""
+    from tests.oracle_binding import oracle_scene
+    scene_file = scene_path("readme_small")
+    result = str(tmp_path / "gathered.npy")
+    mp.spawn(_shared_scene_worker, args=(3, _free_port(), scene_file, str(tmp_path / "flat"), (16, 16), result), nprocs=3, join=True)
+    hs = capi.HostScene.load(scene_file).build()
+    whole = oracle_scene(hs.desc, threads=4)
+    ref, _ = whole.render(seed=7)
+    whole.close()
+    assert np.array_equal(np.load(result).view(np.uint32), np.asarray(ref, dtype=np.float32).view(np.uint32))
