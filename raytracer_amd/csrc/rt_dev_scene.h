@@ -76,6 +76,7 @@ struct DevScene {
   int32_t numPrims;
   int32_t hasSpheres;
   int32_t boxesFinite;  // every node box coordinate is finite (enables the min/max slab test)
+  float cutEps;         // point-light queries: how far outside its box an accepted hit point can lie (see buildScene); 0 = unknown, no box is culled against the bulb
   int32_t numPlanes;
   const DevPlane *planes;
   // shading

@@ -317,6 +317,7 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
   uint32_t item = 0;
   V3 o = v3(0, 0, 0), nd = o, inv = o;
   float tBest = kInf, bulbDist = 0.0f;
+  float cutLimit = kInf;   // TRAV_POINT_LIGHT: boxes entered at or beyond this parameter (units of |d|) hold no occluder (see prepare)
   float tPlane = kInf;     // closest plane along the ray (found when the query was prepared)
   int32_t planeBest = -1;
   int32_t primBest = -1, cur = 0, pi = 0, pe = 0;
@@ -455,7 +456,7 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
       }
       bool pooled = false;
       V3 qo = v3(0, 0, 0), qnd = qo, qinv = qo;
-      float qtPlane = kInf, qbulb = 0.0f;
+      float qtPlane = kInf, qbulb = 0.0f, qcut = kInf;
       int32_t qplane = -1, qfirst = kNoBvh;
       int qmode = TRAV_CLOSEST;
       bool qfinite = true;
@@ -481,15 +482,34 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
             deliver(qitem, true, qmode, qtPlane, S.numPrims + qplane, qtPlane, qplane, qo, qnd);
           } else {
             // A point-light query only asks whether the closest hit lies nearer than the bulb, and ends as soon as an
-            // accepted hit is (RT_PRIM_STEP). Boxes are NOT culled against the bulb's distance: the slab test is no safe
-            // lower bound for that (a ray almost parallel to a flat box: the rounding of (box - origin) times a huge
-            // reciprocal moves the entry distance by several percent), and a box culled by mistake loses an occluder.
+            // accepted hit is (RT_PRIM_STEP). Which boxes may be skipped because they lie beyond the bulb (parameter 1 in
+            // units of |d|)? The slab test's entry parameter alone is no safe bound: an object test accepts a hit whose
+            // point P = o + u d lies up to eps OUTSIDE the object's box (rounding of the barycentric test), and on an axis
+            // the ray is almost parallel to, eps of position is eps / |d_k| of parameter: several percent, or anything.
+            // What does hold, per axis, is u >= entry_k - eps / |d_k|; with margin = eps * max_k |1 / d_k| the box's entry
+            // parameter (the largest entry_k) exceeds the u of every hit inside by at most `margin`. A box entered beyond
+            // 1 + 2 margin therefore holds only hits beyond 1 + margin: none of them is an occluder, and none of them can
+            // lower the closest hit below what it takes to cull a box that still may hold one (entry below 1 + margin), so
+            // skipping them changes neither the answer nor what the reference's own culling (src/acceleration/BVH.cpp:302-305)
+            // would have visited among the boxes that matter. Rays with a margin above 2 % get no cut, nor do bulbs nearer
+            // than one unit: there t (in units of 1) is smaller than the parameter, and a hit BEYOND the bulb can make the
+            // reference cull a box in front of it.
             if (S.rootRef != kNoBvh) {
               qinv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // src/acceleration/BVH.cpp:293
-              qfinite = S.boxesFinite && isfinite(qinv.x) && isfinite(qinv.y) && isfinite(qinv.z) && qinv.x != 0 && qinv.y != 0 &&
-                        qinv.z != 0 && isfinite(qo.x) && isfinite(qo.y) && isfinite(qo.z);
+              const bool rayFinite = isfinite(qinv.x) && isfinite(qinv.y) && isfinite(qinv.z) && qinv.x != 0 && qinv.y != 0 && qinv.z != 0 &&
+                                     isfinite(qo.x) && isfinite(qo.y) && isfinite(qo.z);
+              qfinite = S.boxesFinite && rayFinite;
+              if (RUNTIME_MODE && qmode == TRAV_POINT_LIGHT && S.cutEps > 0.0f && rayFinite && qbulb >= 1.0f) {  // cutEps > 0: every box is finite
+                const float eps = S.cutEps + 9.5367431640625e-07f * (fabsf(qo.x) + fabsf(qo.y) + fabsf(qo.z) + qbulb);  // 2^-20
+                const float margin = eps * __builtin_fmaxf(__builtin_fmaxf(fabsf(qinv.x), fabsf(qinv.y)), fabsf(qinv.z));
+                if (margin <= 0.02f) {
+                  // kept as the upper 16 bits of a float, rounded up (a larger limit only culls less)
+                  const uint32_t bits = (__float_as_uint(1.0f + 2.0f * margin + 1.52587890625e-05f) + 0xffffu) & 0xffff0000u;
+                  qcut = __uint_as_float(bits);
+                }
+              }
               float rootDist = intersectAABB(qo, qinv, S.rootMin[0], S.rootMin[1], S.rootMin[2], S.rootMax[0], S.rootMax[1], S.rootMax[2]);
-              if (rootDist < kInf) qfirst = S.rootRef;
+              if (rootDist < qcut) qfirst = S.rootRef;
             }
             if (qfirst == kNoBvh) deliver(qitem, false, qmode, kInf, -1, qtPlane, qplane, qo, qnd);  // nothing to traverse
             else pooled = true;
@@ -508,7 +528,8 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
         q[9 * kPoolSlots] = __float_as_uint(RUNTIME_MODE ? qbulb : qtPlane);
         q[10 * kPoolSlots] = qitem;
         q[11 * kPoolSlots] = (uint32_t)qfirst;
-        q[12 * kPoolSlots] = (uint32_t)(qplane + 1) | ((uint32_t)qmode << 16) | ((uint32_t)qfinite << 20);
+        // a visibility query has no plane to remember: its cut limit (upper half of a float) travels in those 16 bits
+        q[12 * kPoolSlots] = (RUNTIME_MODE ? (__float_as_uint(qcut) >> 16) : (uint32_t)(qplane + 1)) | ((uint32_t)qmode << 16) | ((uint32_t)qfinite << 20);
       }
       poolCount += (uint32_t)__popcll(mPooled);
     }
@@ -528,6 +549,7 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
           const int32_t first = (int32_t)q[11 * kPoolSlots];
           const uint32_t packed = q[12 * kPoolSlots];
           planeBest = RUNTIME_MODE ? -1 : (int32_t)(packed & 0xffffu) - 1;
+          if (RUNTIME_MODE) cutLimit = __uint_as_float(packed << 16);
           mode = (int)((packed >> 16) & 0xfu);
           finite = ((packed >> 20) & 1u) != 0u;
           tBest = kInf; primBest = -1; sp = 0; lo = 0;
@@ -559,7 +581,7 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
           const float4 *N = reinterpret_cast<const float4 *>(nodeBase + ((uint32_t)cur << 6));
           a = N[0]; b = N[1]; c = N[2];
           r = reinterpret_cast<const int4 *>(N)[3];
-          const float lim = tBest;
+          const float lim = RUNTIME_MODE ? __builtin_fminf(tBest, cutLimit) : tBest;  // stack entries were pushed below cutLimit already
           if (waveExact) innerStep<true, K, BLOCK>(a, b, c, r, o, inv, lim, stackCol, spill, sp, lo, cur, pi, pe, op);  // wave-uniform: valid for every ray, just slower
           else innerStep<false, K, BLOCK>(a, b, c, r, o, inv, lim, stackCol, spill, sp, lo, cur, pi, pe, op);
         }

@@ -1126,10 +1126,43 @@ int buildScene(RtScene *s, const RtSceneDesc *d) {
   }
   dev.numPrims = d->numPrims;
   dev.hasSpheres = hasSpheres;
+  // How far outside its object's box can the point of an ACCEPTED hit lie? (What a point-light query needs to know before
+  // it may skip a box beyond the bulb: rt_dev_traverse.h.) A sphere hit lies on the sphere up to the rounding of its
+  // coordinates. A triangle hit passes b2 = dot(e1, P - p1), b3 = dot(e2, P - p1) in [0, 1] (src/scene/Object.cpp:203-208):
+  // the rounding of those sums (and of P - p1, in units of the coordinates' size) moves the accepted region by
+  // |e| * size * 2^-22 barycentric units, i.e. by that times the triangle's diameter. G = |e| * diameter is the triangle's
+  // aspect ratio, 1 for a well-shaped one. A triangle whose edge vectors are not finite (zero area: the reference's
+  // set-up divides by zero, Object.cpp:191-192) is accepted wherever a ray meets its plane: no bound, no cut (cutEps = 0).
+  {
+    double extent = 0.0, worst = 0.0;
+    bool bounded = d->numNodes > 0 || buildOnDevice;
+    for (size_t i = 0; i < n && bounded; ++i) {
+      const float *h = d->primHit + i * 12;
+      if (d->primKind[i] == RT_PRIM_SPHERE) {
+        for (int k = 0; k < 3; ++k) extent = std::max(extent, (double)std::fabs(h[k]) + std::fabs(h[3]));
+        continue;
+      }
+      const double nx = h[3], ny = h[4], nz = h[5], ax = h[6], ay = h[7], az = h[8], bx = h[9], by = h[10], bz = h[11];
+      // the edges u = p2 - p1, v = p3 - p1 from their dual vectors e1, e2 (e1.u = 1, e1.v = 0, e2.u = 0, e2.v = 1, all in the plane)
+      const double c1[3] = {by * nz - bz * ny, bz * nx - bx * nz, bx * ny - by * nx};  // e2 x n
+      const double c2[3] = {ny * az - nz * ay, nz * ax - nx * az, nx * ay - ny * ax};  // n x e1
+      const double d1 = ax * c1[0] + ay * c1[1] + az * c1[2], d2 = bx * c2[0] + by * c2[1] + bz * c2[2];
+      const double u[3] = {c1[0] / d1, c1[1] / d1, c1[2] / d1}, v[3] = {c2[0] / d2, c2[1] / d2, c2[2] / d2};
+      auto len = [](double x, double y, double z) { return std::sqrt(x * x + y * y + z * z); };
+      const double diam = std::max({len(u[0], u[1], u[2]), len(v[0], v[1], v[2]), len(u[0] - v[0], u[1] - v[1], u[2] - v[2])});
+      const double G = std::max(len(ax, ay, az), len(bx, by, bz)) * diam;
+      if (!std::isfinite(G) || !std::isfinite(diam)) { bounded = false; break; }
+      worst = std::max(worst, G);
+      for (int k = 0; k < 3; ++k) extent = std::max(extent, std::fabs((double)h[k]) + diam);
+    }
+    const double eps = std::ldexp(std::max(1.0, worst) * extent, -20);
+    dev.cutEps = (bounded && std::isfinite(eps) && eps > 0.0 && eps < 1e30) ? (float)eps : 0.0f;
+    if (std::getenv("RT_NO_POINT_LIGHT_CUT")) dev.cutEps = 0.0f;
+  }
   dev.boxesFinite = std::getenv("RT_EXACT_SLAB_TEST") ? 0 : 1;  // debugging aid: force the compare-and-select slab test
   for (int32_t i = 0; i < d->numNodes; ++i)
     for (int k = 0; k < 3; ++k)
-      if (!std::isfinite(d->nodes[i].aabbMin[k]) || !std::isfinite(d->nodes[i].aabbMax[k])) dev.boxesFinite = 0;
+      if (!std::isfinite(d->nodes[i].aabbMin[k]) || !std::isfinite(d->nodes[i].aabbMax[k])) { dev.boxesFinite = 0; dev.cutEps = 0.0f; }
   int rc;
   if ((rc = upload(s, nodes.data(), nodes.size(), &dev.nodes))) return rc;
   if ((rc = upload(s, primHit.data(), primHit.size(), &dev.primHit))) return rc;
@@ -1168,7 +1201,7 @@ int buildScene(RtScene *s, const RtSceneDesc *d) {
     dev.rootRef = bvh.rootRef;
     std::memcpy(dev.rootMin, bvh.rootMin, 12);
     std::memcpy(dev.rootMax, bvh.rootMax, 12);
-    if (!bvh.boxesFinite) dev.boxesFinite = 0;
+    if (!bvh.boxesFinite) { dev.boxesFinite = 0; dev.cutEps = 0.0f; }
     s->bvhBuildMs = bvh.buildMs;
     order = bvh.order;
     if ((rc = reorder(reinterpret_cast<const void **>(&dev.primHit), 12))) return rc;
