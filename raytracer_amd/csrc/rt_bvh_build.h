@@ -34,4 +34,10 @@ struct DeviceBvh {
 // positions). Returns false with a message on failure; nothing is left allocated then.
 bool buildLbvh(hipStream_t stream, const float *aabbMin, const float *aabbMax, int32_t n, DeviceBvh *out, std::string &error);
 
+// The same interface, another tree: the objects in Morton order are clustered bottom-up by surface area (parallel
+// locally-ordered clustering, rt_ploc.h), which gives about the quality of the reference's binned-SAH build
+// (src/acceleration/BVH.cpp:72-140) in some tens of milliseconds. Inputs it is unsuitable for (objects that pair up too
+// slowly, a tree deeper than the traversal stack) are reported with *unsuitable = true: the caller then builds the linear BVH.
+bool buildPloc(hipStream_t stream, const float *aabbMin, const float *aabbMax, int32_t n, DeviceBvh *out, std::string &error, bool *unsuitable);
+
 }  // namespace rtd

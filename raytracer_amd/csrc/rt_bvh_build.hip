@@ -13,9 +13,11 @@
 // Depth: at most 39 levels of code bits plus log2(n) <= 24 levels inside a run of equal codes, below the traversal
 // stack's 64 entries.
 #include "rt_bvh_build.h"
+#include "rt_ploc.h"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>  // before rocprim: its texture iterator calls the host memset
 #include <vector>
 
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(kBuildBlock) void k_mark_records(const int32_t *fir
 }
 
 __device__ __forceinline__ int32_t leafRef(int32_t start, int32_t count) { return (int32_t)(0x80000000u | ((uint32_t)count << 24) | (uint32_t)start); }
+inline int32_t leafRefHost(int32_t start, int32_t count) { return (int32_t)(0x80000000u | ((uint32_t)count << 24) | (uint32_t)start); }
 
 __global__ __launch_bounds__(kBuildBlock) void k_emit(const float *aabbMin, const float *aabbMax, const uint32_t *order, int32_t numInternal,
                                                       const uint32_t *left, const uint32_t *right, const int32_t *first, const int32_t *last,
@@ -219,6 +222,107 @@ struct Scratch {  // everything the build allocates besides its two results; fre
     return true;
   }
 };
+
+// ---------------------------------------------------------------------------------------------------- clustering build
+// Kernels around the per-element steps of rt_ploc.h (one thread per element).
+static_assert(sizeof(ploc::Box) == sizeof(Box), "one box layout");
+
+__global__ __launch_bounds__(kBuildBlock) void k_ploc_init(const float *aabbMin, const float *aabbMax, const uint32_t *order, int32_t n,
+                                                           ploc::Box *nodeBox, uint32_t *clusters, int32_t *parent, uint32_t *objects,
+                                                           uint32_t *records) {
+  int32_t i = blockIdx.x * kBuildBlock + threadIdx.x;
+  if (i >= n) return;
+  const Box b = objectBox(aabbMin, aabbMax, order[i]);
+  ploc::Box pb;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { pb.mn[k] = b.mn[k]; pb.mx[k] = b.mx[k]; }
+  nodeBox[i] = pb;
+  clusters[i] = (uint32_t)i;
+  parent[i] = ploc::kNoParent;
+  objects[i] = 1u;
+  records[i] = 0u;
+}
+
+__global__ __launch_bounds__(kBuildBlock) void k_ploc_nearest(uint32_t count, int radius, const uint32_t *clusters, const ploc::Box *nodeBox,
+                                                              uint32_t *partner) {
+  uint32_t i = blockIdx.x * kBuildBlock + threadIdx.x;
+  if (i < count) ploc::nearest(i, count, radius, clusters, nodeBox, partner);
+}
+
+__global__ __launch_bounds__(kBuildBlock) void k_ploc_merge(uint32_t count, const uint32_t *clusters, const uint32_t *partner, ploc::Box *nodeBox,
+                                                            uint32_t n, uint32_t *child0, uint32_t *child1, int32_t *parent, uint32_t *clustersOut,
+                                                            uint32_t *keep, uint32_t *made) {
+  uint32_t i = blockIdx.x * kBuildBlock + threadIdx.x;
+  if (i >= count) return;
+  keep[i] = ploc::merge(i, clusters, partner, nodeBox, n, child0, child1, parent, clustersOut, [=]() { return n + atomicAdd(made, 1u); });
+}
+
+__global__ __launch_bounds__(kBuildBlock) void k_ploc_compact(uint32_t count, const uint32_t *keep, const uint32_t *pos, const uint32_t *clustersOut,
+                                                              uint32_t *clustersNext, uint32_t *countOut) {
+  uint32_t i = blockIdx.x * kBuildBlock + threadIdx.x;
+  if (i >= count) return;
+  if (keep[i]) clustersNext[pos[i]] = clustersOut[i];  // pos[i] < number kept <= count
+  if (i == count - 1u) *countOut = pos[i] + keep[i];
+}
+
+__global__ __launch_bounds__(kBuildBlock) void k_ploc_count(uint32_t n, const uint32_t *child0, const uint32_t *child1, const int32_t *parent,
+                                                            uint32_t *arrived, uint32_t *objects, uint32_t *records) {
+  uint32_t i = blockIdx.x * kBuildBlock + threadIdx.x;
+  if (i >= n) return;
+  // the first thread at a node publishes what it wrote below and stops; the second one sees both children's figures
+  ploc::countUp(i, n, kLbvhLeafMax, child0, child1, parent, objects, records, [=](uint32_t k) {
+    __threadfence();
+    const bool second = atomicAdd(&arrived[k], 1u) == 1u;
+    __threadfence();
+    return second;
+  });
+}
+
+__global__ __launch_bounds__(kBuildBlock) void k_ploc_place(uint32_t n, const uint32_t *child0, const uint32_t *child1, const int32_t *parent,
+                                                            const uint32_t *objects, const uint32_t *records, const uint32_t *order,
+                                                            uint32_t *firstObject, uint32_t *recordIndex, uint32_t *treeOrder, uint32_t *maxDepth) {
+  uint32_t v = blockIdx.x * kBuildBlock + threadIdx.x;
+  if (v >= 2u * n - 1u) return;
+  const ploc::Place p = ploc::place(v, n, child0, child1, parent, objects, records);
+  firstObject[v] = p.firstObject;
+  recordIndex[v] = p.recordIndex;
+  if (v < n) {
+    if (p.firstObject < n) treeOrder[p.firstObject] = order[v];  // the objects' places are a permutation of 0 .. n-1 (tests/cpp/ploc_check.cpp)
+    else atomicMax(maxDepth, 0xffffffffu);                        // never seen; reported as an unusable tree rather than written out of bounds
+  }
+  else if (records[v] > 0u) atomicMax(maxDepth, p.depth);
+}
+
+__global__ __launch_bounds__(kBuildBlock) void k_ploc_emit(uint32_t n, const uint32_t *child0, const uint32_t *child1, const uint32_t *objects,
+                                                           const uint32_t *records, const uint32_t *firstObject, const uint32_t *recordIndex,
+                                                           const ploc::Box *nodeBox, uint32_t numRecords, float4 *out, uint32_t *nonFinite) {
+  uint32_t k = blockIdx.x * kBuildBlock + threadIdx.x;
+  if (k >= n - 1u) return;
+  const uint32_t id = n + k;
+  if (records[id] == 0u) return;  // inside a leaf
+  if (recordIndex[id] >= numRecords) { atomicOr(nonFinite, 2u); return; }  // never seen; the host refuses the tree
+  const uint32_t child[2] = {child0[k], child1[k]};
+  ploc::Box b[2];
+  int32_t ref[2];
+  bool bad = false;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    b[c] = nodeBox[child[c]];
+    ref[c] = records[child[c]] > 0u ? (int32_t)recordIndex[child[c]] : leafRef((int32_t)firstObject[child[c]], (int32_t)objects[child[c]]);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) bad |= !isfinite(b[c].mn[a]) || !isfinite(b[c].mx[a]);
+  }
+  if (bad) atomicOr(nonFinite, 1u);
+  float4 *R = out + 4 * (int64_t)recordIndex[id];
+  R[0] = make_float4(b[0].mn[0], b[0].mn[1], b[0].mn[2], b[0].mx[0]);
+  R[1] = make_float4(b[0].mx[1], b[0].mx[2], b[1].mn[0], b[1].mn[1]);
+  R[2] = make_float4(b[1].mn[2], b[1].mx[0], b[1].mx[1], b[1].mx[2]);
+  R[3] = make_float4(__int_as_float(ref[0]), __int_as_float(ref[1]), 0.0f, 0.0f);
+}
+
+constexpr int kPlocRadius = 16;       // positions searched to either side for a partner
+constexpr uint32_t kPlocMaxRounds = 256;  // inputs that pair up slower than this (boxes growing geometrically along a line) get the linear BVH
+constexpr uint32_t kPlocMaxDepth = 61;    // records above the deepest record; its leaves then sit at depth <= 63 of the 64-entry traversal stack
 
 }  // namespace
 
@@ -310,6 +414,116 @@ bool buildLbvh(hipStream_t stream, const float *aabbMin, const float *aabbMax, i
   out->boxesFinite = hostFlags[0] == 0u;
   for (int k = 0; k < 3; ++k) out->boxesFinite = out->boxesFinite && std::isfinite(rootBox.mn[k]) && std::isfinite(rootBox.mx[k]);
   if ((e = hipGetLastError()) != hipSuccess) return fail("kernel launch", e);
+  if (hipEventElapsedTime(&out->buildMs, ev.a, ev.b) != hipSuccess) out->buildMs = 0.0f;
+  std::memcpy(out->rootMin, rootBox.mn, 12);
+  std::memcpy(out->rootMax, rootBox.mx, 12);
+  return true;
+}
+
+bool buildPloc(hipStream_t stream, const float *aabbMin, const float *aabbMax, int32_t n, DeviceBvh *out, std::string &error, bool *unsuitable) {
+  *out = DeviceBvh{};
+  *unsuitable = false;
+  if (n < 1 || n > (1 << 24)) { error = "the device BVH build takes 1 .. 2^24 objects"; return false; }
+  auto fail = [&](const char *what, hipError_t e) {
+    error = std::string("device BVH build (clustering): ") + what + (e != hipSuccess ? std::string(": ") + hipGetErrorString(e) : std::string());
+    if (out->records) (void)hipFree(out->records);
+    if (out->order) (void)hipFree(out->order);
+    *out = DeviceBvh{};
+    return false;
+  };
+  Scratch sc;
+  const uint32_t un = (uint32_t)n, numNodes = 2u * un - 1u, numInternal = un - 1u;
+  uint32_t *bounds = nullptr, *vals = nullptr, *order = nullptr, *clusterA = nullptr, *clusterB = nullptr, *clusterOut = nullptr, *partner = nullptr,
+           *keep = nullptr, *pos = nullptr, *child0 = nullptr, *child1 = nullptr, *objects = nullptr, *records = nullptr, *firstObject = nullptr,
+           *recordIndex = nullptr, *arrived = nullptr, *words = nullptr;
+  uint64_t *keys = nullptr, *keysSorted = nullptr;
+  int32_t *parent = nullptr;
+  ploc::Box *nodeBox = nullptr;
+  if (!sc.alloc(&bounds, 8) || !sc.alloc(&keys, un) || !sc.alloc(&keysSorted, un) || !sc.alloc(&vals, un) || !sc.alloc(&order, un) ||
+      !sc.alloc(&clusterA, un) || !sc.alloc(&clusterB, un) || !sc.alloc(&clusterOut, un) || !sc.alloc(&partner, un) || !sc.alloc(&keep, un) ||
+      !sc.alloc(&pos, un) || !sc.alloc(&child0, numInternal) || !sc.alloc(&child1, numInternal) || !sc.alloc(&objects, numNodes) ||
+      !sc.alloc(&records, numNodes) || !sc.alloc(&firstObject, numNodes) || !sc.alloc(&recordIndex, numNodes) || !sc.alloc(&arrived, numInternal) ||
+      !sc.alloc(&parent, numNodes) || !sc.alloc(&nodeBox, numNodes) || !sc.alloc(&words, 8))
+    return fail("out of device memory", hipSuccess);
+  uint32_t *made = words, *countOut = words + 1, *maxDepth = words + 2, *nonFinite = words + 3;
+  hipError_t e;
+  if ((e = hipMalloc(reinterpret_cast<void **>(&out->order), (size_t)un * sizeof(uint32_t))) != hipSuccess) return fail("hipMalloc", e);
+  struct Events {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  } ev;
+  if ((e = hipEventCreate(&ev.a)) != hipSuccess || (e = hipEventCreate(&ev.b)) != hipSuccess) return fail("hipEventCreate", e);
+  if ((e = hipEventRecord(ev.a, stream)) != hipSuccess) return fail("hipEventRecord", e);
+  // ---- Morton order of the objects (as for the linear BVH)
+  k_init_bounds<<<1, 64, 0, stream>>>(bounds);
+  k_centre_bounds<<<gridOf(n), kBuildBlock, 0, stream>>>(aabbMin, aabbMax, n, bounds);
+  k_morton<<<gridOf(n), kBuildBlock, 0, stream>>>(aabbMin, aabbMax, n, bounds, keys, vals);
+  if ((e = hipGetLastError()) != hipSuccess) return fail("launch of the bounds / Morton-code kernels", e);
+  size_t sortBytes = 0, scanBytes = 0;
+  if ((e = rocprim::radix_sort_pairs(nullptr, sortBytes, keys, keysSorted, vals, order, (size_t)un, 0, kMortonBits, stream)) != hipSuccess)
+    return fail("radix sort (size query)", e);
+  if ((e = rocprim::exclusive_scan(nullptr, scanBytes, keep, pos, 0u, (size_t)un, rocprim::plus<uint32_t>(), stream)) != hipSuccess)
+    return fail("scan (size query)", e);
+  unsigned char *temp = nullptr;
+  if (!sc.alloc(&temp, std::max(sortBytes, scanBytes))) return fail("out of device memory", hipSuccess);
+  if ((e = rocprim::radix_sort_pairs(temp, sortBytes, keys, keysSorted, vals, order, (size_t)un, 0, kMortonBits, stream)) != hipSuccess)
+    return fail("radix sort", e);
+  // ---- clustering rounds
+  if ((e = hipMemsetAsync(words, 0, 8 * sizeof(uint32_t), stream)) != hipSuccess) return fail("hipMemsetAsync", e);
+  k_ploc_init<<<gridOf(n), kBuildBlock, 0, stream>>>(aabbMin, aabbMax, order, n, nodeBox, clusterA, parent, objects, records);
+  if ((e = hipGetLastError()) != hipSuccess) return fail("launch of the set-up kernel", e);
+  uint32_t count = un, rounds = 0;
+  uint32_t *cur = clusterA, *next = clusterB;
+  int radius = kPlocRadius;
+  if (const char *x = std::getenv("RT_PLOC_RADIUS")) radius = std::min(256, std::max(1, std::atoi(x)));  // experiments
+  while (count > 1u) {
+    if (++rounds > kPlocMaxRounds) { *unsuitable = true; return fail("the objects pair up too slowly", hipSuccess); }
+    k_ploc_nearest<<<gridOf(count), kBuildBlock, 0, stream>>>(count, radius, cur, nodeBox, partner);
+    k_ploc_merge<<<gridOf(count), kBuildBlock, 0, stream>>>(count, cur, partner, nodeBox, un, child0, child1, parent, clusterOut, keep, made);
+    if ((e = hipGetLastError()) != hipSuccess) return fail("launch of a clustering round", e);
+    size_t bytes = scanBytes;
+    if ((e = rocprim::exclusive_scan(temp, bytes, keep, pos, 0u, (size_t)count, rocprim::plus<uint32_t>(), stream)) != hipSuccess) return fail("scan", e);
+    k_ploc_compact<<<gridOf(count), kBuildBlock, 0, stream>>>(count, keep, pos, clusterOut, next, countOut);
+    uint32_t left = 0;
+    if ((e = hipMemcpyAsync(&left, countOut, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return fail("copy", e);
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail("clustering round", e);
+    if (left == 0u || left >= count) return fail("a clustering round merged nothing", hipSuccess);  // cannot happen: the best pair over all is mutual
+    count = left;
+    std::swap(cur, next);
+  }
+  // ---- layout: object counts and record counts bottom-up, places top-down, records
+  if ((e = hipMemsetAsync(arrived, 0, (size_t)std::max(1u, numInternal) * sizeof(uint32_t), stream)) != hipSuccess) return fail("hipMemsetAsync", e);
+  uint32_t root = 0;
+  if ((e = hipMemcpyAsync(&root, cur, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return fail("copy", e);
+  if (numInternal > 0) k_ploc_count<<<gridOf(n), kBuildBlock, 0, stream>>>(un, child0, child1, parent, arrived, objects, records);
+  k_ploc_place<<<gridOf(numNodes), kBuildBlock, 0, stream>>>(un, child0, child1, parent, objects, records, order, firstObject, recordIndex, out->order, maxDepth);
+  if ((e = hipGetLastError()) != hipSuccess) return fail("launch of the layout kernels", e);
+  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail("layout kernels", e);
+  if (root >= numNodes) return fail("no root", hipSuccess);
+  uint32_t numRecords = 0, rootObjects = 0, hostWords[4] = {0, 0, 0, 0};
+  ploc::Box rootBox{};
+  if ((e = hipMemcpyAsync(&numRecords, records + root, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return fail("copy", e);
+  if ((e = hipMemcpyAsync(&rootObjects, objects + root, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return fail("copy", e);
+  if ((e = hipMemcpyAsync(&rootBox, nodeBox + root, sizeof rootBox, hipMemcpyDeviceToHost, stream)) != hipSuccess) return fail("copy", e);
+  if ((e = hipMemcpyAsync(hostWords, words, sizeof hostWords, hipMemcpyDeviceToHost, stream)) != hipSuccess) return fail("copy", e);
+  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail("copy", e);
+  if (hostWords[0] != numInternal || rootObjects != un) return fail("the tree does not hold every object once", hipSuccess);
+  if (hostWords[2] > kPlocMaxDepth) { *unsuitable = true; return fail("tree deeper than the traversal stack", hipSuccess); }
+  if (numRecords > numInternal) return fail("number of records", hipSuccess);
+  out->numRecords = (int32_t)numRecords;
+  if ((e = hipMalloc(reinterpret_cast<void **>(&out->records), std::max<size_t>(1, (size_t)numRecords) * 64)) != hipSuccess) return fail("hipMalloc", e);
+  if (numRecords > 0) {
+    k_ploc_emit<<<gridOf(numInternal), kBuildBlock, 0, stream>>>(un, child0, child1, objects, records, firstObject, recordIndex, nodeBox, numRecords, out->records, nonFinite);
+    if ((e = hipGetLastError()) != hipSuccess) return fail("launch of the record kernel", e);
+  }
+  out->rootRef = numRecords > 0 ? 0 : leafRefHost(0, n);  // the root is record 0 (pre-order), or one leaf
+  if ((e = hipEventRecord(ev.b, stream)) != hipSuccess) return fail("hipEventRecord", e);
+  uint32_t flag = 0;
+  if ((e = hipMemcpyAsync(&flag, nonFinite, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return fail("copy", e);
+  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail("record kernel", e);
+  if (flag & 2u) return fail("record index out of range", hipSuccess);
+  out->boxesFinite = flag == 0u;
+  for (int k = 0; k < 3; ++k) out->boxesFinite = out->boxesFinite && std::isfinite(rootBox.mn[k]) && std::isfinite(rootBox.mx[k]);
   if (hipEventElapsedTime(&out->buildMs, ev.a, ev.b) != hipSuccess) out->buildMs = 0.0f;
   std::memcpy(out->rootMin, rootBox.mn, 12);
   std::memcpy(out->rootMax, rootBox.mx, 12);

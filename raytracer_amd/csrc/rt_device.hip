@@ -1190,7 +1190,15 @@ int buildScene(RtScene *s, const RtSceneDesc *d) {
     if ((rc = upload(s, d->primAabbMax, n * 3, &dMax))) return rc;
     DeviceBvh bvh;
     std::string err;
-    if (!buildLbvh(s->stream, dMin, dMax, d->numPrims, &bvh, err)) return failMsg(RT_ERR_DEVICE, err);
+    // Clustering by surface area unless RT_DEVICE_BVH=lbvh asks for the linear BVH, which is also what inputs get that the
+    // clustering is unsuitable for.
+    const char *kind = std::getenv("RT_DEVICE_BVH");
+    bool built = false, unsuitable = false;
+    if (!(kind && std::strcmp(kind, "lbvh") == 0)) {
+      built = buildPloc(s->stream, dMin, dMax, d->numPrims, &bvh, err, &unsuitable);
+      if (!built && !unsuitable) return failMsg(RT_ERR_DEVICE, err);
+    }
+    if (!built && !buildLbvh(s->stream, dMin, dMax, d->numPrims, &bvh, err)) return failMsg(RT_ERR_DEVICE, err);
     s->allocs.push_back(bvh.records);
     s->allocs.push_back(bvh.order);
     for (const float *p : {dMin, dMax}) {

@@ -468,6 +468,32 @@ def test_bvh_built_on_the_device(name, scenes, scene_path):
         lb.close(); raw.close()
 
 
+def test_linear_bvh_is_still_there(scenes, scene_path):
+    """The device build clusters by surface area; inputs it is unsuitable for get the linear BVH, which RT_DEVICE_BVH=lbvh
+    also selects. Both trees give the host tree's t bits; they are different trees (different build, usually different
+    record counts are not visible here, but the build of the linear one is the faster)."""
+    hs, dev, _ = scenes("mesh70k")
+    raw = capi.HostScene.load(scene_path("mesh70k")).flatten_without_bvh()
+    clustered = capi.device_scene(raw.desc)
+    assert "RT_DEVICE_BVH" not in os.environ
+    os.environ["RT_DEVICE_BVH"] = "lbvh"
+    try:
+        linear = capi.device_scene(raw.desc)
+    finally:
+        del os.environ["RT_DEVICE_BVH"]
+    try:
+        _, t0 = dev.trace_primary()
+        for other in (clustered, linear):
+            assert other.bvh_build_ms() > 0
+            assert np.array_equal(t0.view(np.uint32), other.trace_primary()[1].view(np.uint32))
+        o, d = _unit_or_longer_rays(100_000, 13)
+        want = dev.trace_closest(o, d)[1].view(np.uint32)
+        assert np.array_equal(want, clustered.trace_closest(o, d)[1].view(np.uint32))
+        assert np.array_equal(want, linear.trace_closest(o, d)[1].view(np.uint32))
+    finally:
+        clustered.close(); linear.close(); raw.close()
+
+
 def test_device_bvh_build_on_degenerate_input():
     """Inputs that stress the radix tree: thousands of objects at the same place (one Morton code: the tree is decided by
     position alone), one, two and five objects, a mesh whose triangles are all NaN among regular spheres. Hits through the

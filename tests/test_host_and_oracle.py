@@ -483,6 +483,18 @@ def test_host_parallel_loops_cover_every_index_and_hand_exceptions_to_the_caller
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
 
 
+def test_clustering_steps_of_the_gpu_bvh_build_on_the_cpu(tmp_path):
+    """raytracer_amd/csrc/rt_ploc.h holds the per-element steps of the GPU BVH build (partner search, merge, counts, places);
+    tests/cpp/ploc_check.cpp drives the same functions from plain loops under the address and undefined-behaviour
+    sanitizers: one object, two, five, thousands of identical boxes, random soups, boxes growing geometrically, NaN and
+    infinite boxes. Every object gets one place, every record one index, boxes hold their children's, every round merges."""
+    exe = str(tmp_path / "ploc_check")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                    "-I" + os.path.join(REPO, "raytracer_amd", "csrc"), os.path.join(REPO, "tests", "cpp", "ploc_check.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_flattened_scene_survives_the_trip_through_files(tmp_path, scene_path):
     """raytracer_amd/desc_io.py: the arrays one process flattens are what another maps — same records, so the CPU
     restatement renders the same frame and finds the same hits from either description (textures, texture coordinates
