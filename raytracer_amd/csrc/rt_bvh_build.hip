@@ -14,6 +14,7 @@
 // stack's 64 entries.
 #include "rt_bvh_build.h"
 #include "rt_ploc.h"
+#include "rt_top_tree.h"
 
 #include <algorithm>
 #include <cmath>
@@ -320,6 +321,22 @@ __global__ __launch_bounds__(kBuildBlock) void k_ploc_emit(uint32_t n, const uin
   R[3] = make_float4(__int_as_float(ref[0]), __int_as_float(ref[1]), 0.0f, 0.0f);
 }
 
+// what the host needs of the clusters that are left when the clustering stops: box, object count, record count
+__global__ __launch_bounds__(kBuildBlock) void k_ploc_gather_roots(uint32_t count, const uint32_t *clusters, const ploc::Box *nodeBox,
+                                                                   const uint32_t *objects, const uint32_t *records, ploc::Box *outBox,
+                                                                   uint32_t *outObjects, uint32_t *outRecords) {
+  uint32_t k = blockIdx.x * kBuildBlock + threadIdx.x;
+  if (k >= count) return;
+  const uint32_t id = clusters[k];
+  outBox[k] = nodeBox[id]; outObjects[k] = objects[id]; outRecords[k] = records[id];
+}
+__global__ __launch_bounds__(kBuildBlock) void k_ploc_set_parents(uint32_t count, const uint32_t *clusters, const int32_t *parentOfItem, uint32_t numNodes,
+                                                                  int32_t *parent) {
+  uint32_t k = blockIdx.x * kBuildBlock + threadIdx.x;
+  if (k < count && clusters[k] < numNodes) parent[clusters[k]] = parentOfItem[k];
+}
+
+constexpr uint32_t kPlocTopClusters = 2048;  // the clustering stops at this many clusters; the levels above them are built top-down on the host
 constexpr int kPlocRadius = 16;       // positions searched to either side for a partner
 constexpr uint32_t kPlocMaxRounds = 256;  // inputs that pair up slower than this (boxes growing geometrically along a line) get the linear BVH
 constexpr uint32_t kPlocMaxDepth = 61;    // records above the deepest record; its leaves then sit at depth <= 63 of the 64-entry traversal stack
@@ -476,7 +493,9 @@ bool buildPloc(hipStream_t stream, const float *aabbMin, const float *aabbMax, i
   uint32_t *cur = clusterA, *next = clusterB;
   int radius = kPlocRadius;
   if (const char *x = std::getenv("RT_PLOC_RADIUS")) radius = std::min(256, std::max(1, std::atoi(x)));  // experiments
-  while (count > 1u) {
+  uint32_t topTarget = kPlocTopClusters;
+  if (const char *x = std::getenv("RT_PLOC_TOP")) topTarget = (uint32_t)std::min(8192, std::max(1, std::atoi(x)));  // experiments; 1 = clustering to the root
+  while (count > topTarget) {
     if (++rounds > kPlocMaxRounds) { *unsuitable = true; return fail("the objects pair up too slowly", hipSuccess); }
     k_ploc_nearest<<<gridOf(count), kBuildBlock, 0, stream>>>(count, radius, cur, nodeBox, partner);
     k_ploc_merge<<<gridOf(count), kBuildBlock, 0, stream>>>(count, cur, partner, nodeBox, un, child0, child1, parent, clusterOut, keep, made);
@@ -491,11 +510,54 @@ bool buildPloc(hipStream_t stream, const float *aabbMin, const float *aabbMax, i
     count = left;
     std::swap(cur, next);
   }
-  // ---- layout: object counts and record counts bottom-up, places top-down, records
+  // ---- layout: object counts and record counts bottom-up (below the clusters that are left) ...
   if ((e = hipMemsetAsync(arrived, 0, (size_t)std::max(1u, numInternal) * sizeof(uint32_t), stream)) != hipSuccess) return fail("hipMemsetAsync", e);
-  uint32_t root = 0;
-  if ((e = hipMemcpyAsync(&root, cur, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return fail("copy", e);
   if (numInternal > 0) k_ploc_count<<<gridOf(n), kBuildBlock, 0, stream>>>(un, child0, child1, parent, arrived, objects, records);
+  if ((e = hipGetLastError()) != hipSuccess) return fail("launch of the count kernel", e);
+  uint32_t root = 0;
+  if (count == 1u) {
+    if ((e = hipMemcpyAsync(&root, cur, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return fail("copy", e);
+  } else {
+    // ... the levels above them top-down, on the host (rt_top_tree.h): a few thousand boxes out, as many nodes back
+    ploc::Box *topBox = nullptr;
+    uint32_t *topObjects = nullptr, *topRecords = nullptr;
+    int32_t *topParents = nullptr;
+    if (!sc.alloc(&topBox, count) || !sc.alloc(&topObjects, count) || !sc.alloc(&topRecords, count) || !sc.alloc(&topParents, count))
+      return fail("out of device memory", hipSuccess);
+    k_ploc_gather_roots<<<gridOf(count), kBuildBlock, 0, stream>>>(count, cur, nodeBox, objects, records, topBox, topObjects, topRecords);
+    if ((e = hipGetLastError()) != hipSuccess) return fail("launch of the gather kernel", e);
+    std::vector<uint32_t> ids(count), hObjects(count), hRecords(count);
+    std::vector<ploc::Box> hBox(count);
+    uint32_t madeSoFar = 0;
+    if ((e = hipMemcpyAsync(ids.data(), cur, (size_t)count * 4, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(hBox.data(), topBox, (size_t)count * sizeof(ploc::Box), hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(hObjects.data(), topObjects, (size_t)count * 4, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(hRecords.data(), topRecords, (size_t)count * 4, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(&madeSoFar, made, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess)
+      return fail("copy", e);
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail("clustering", e);
+    if (madeSoFar + (count - 1u) != numInternal) return fail("number of internal nodes before the top", hipSuccess);
+    for (uint32_t k = 0; k < count; ++k)
+      if (ids[k] >= numNodes) return fail("cluster id out of range", hipSuccess);
+    const uint32_t firstNew = un + madeSoFar;
+    const ploc::TopTree top = ploc::buildTopTree(ids, hBox, hObjects, hRecords, firstNew, kLbvhLeafMax);
+    const size_t m1 = (size_t)count - 1;
+    if (top.child0.size() != m1 || top.parentOfItem.size() != count) return fail("top tree size", hipSuccess);
+    // new nodes occupy the ids firstNew .. 2n - 2: contiguous in every per-node array
+    if ((e = hipMemcpyAsync(child0 + madeSoFar, top.child0.data(), m1 * 4, hipMemcpyHostToDevice, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(child1 + madeSoFar, top.child1.data(), m1 * 4, hipMemcpyHostToDevice, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(objects + firstNew, top.objects.data(), m1 * 4, hipMemcpyHostToDevice, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(records + firstNew, top.records.data(), m1 * 4, hipMemcpyHostToDevice, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(parent + firstNew, top.parent.data(), m1 * 4, hipMemcpyHostToDevice, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(nodeBox + firstNew, top.box.data(), m1 * sizeof(ploc::Box), hipMemcpyHostToDevice, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(topParents, top.parentOfItem.data(), (size_t)count * 4, hipMemcpyHostToDevice, stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(made, &numInternal, 4, hipMemcpyHostToDevice, stream)) != hipSuccess)
+      return fail("copy", e);
+    k_ploc_set_parents<<<gridOf(count), kBuildBlock, 0, stream>>>(count, cur, topParents, numNodes, parent);
+    if ((e = hipGetLastError()) != hipSuccess) return fail("launch of the parent kernel", e);
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail("top of the tree", e);  // the host vectors above go out of scope
+    root = top.root;
+  }
   k_ploc_place<<<gridOf(numNodes), kBuildBlock, 0, stream>>>(un, child0, child1, parent, objects, records, order, firstObject, recordIndex, out->order, maxDepth);
   if ((e = hipGetLastError()) != hipSuccess) return fail("launch of the layout kernels", e);
   if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail("layout kernels", e);

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "rt_ploc.h"
+#include "rt_top_tree.h"
 
 using namespace rtd::ploc;
 
@@ -27,7 +28,7 @@ bool fail(const char *what, long a = 0, long b = 0) {
   return false;
 }
 
-bool build(const std::vector<Box> &leaves, int radius, uint32_t maxRounds, Tree &t) {
+bool build(const std::vector<Box> &leaves, int radius, uint32_t maxRounds, uint32_t topTarget, Tree &t) {
   const uint32_t n = (uint32_t)leaves.size();
   t.n = n;
   t.box.assign(leaves.begin(), leaves.end());
@@ -39,7 +40,7 @@ bool build(const std::vector<Box> &leaves, int radius, uint32_t maxRounds, Tree 
   for (uint32_t i = 0; i < n; ++i) cur[i] = i;
   uint32_t count = n, made = 0;
   t.rounds = 0;
-  while (count > 1) {
+  while (count > topTarget) {
     if (++t.rounds > maxRounds) return fail("too many rounds", t.rounds, count);
     for (uint32_t i = 0; i < count; ++i) nearest(i, count, radius, cur.data(), t.box.data(), partner.data());
     for (uint32_t i = 0; i < count; ++i)
@@ -57,9 +58,7 @@ bool build(const std::vector<Box> &leaves, int radius, uint32_t maxRounds, Tree 
     count = m;
     cur.swap(next);
   }
-  if (made != n - 1) return fail("number of internal nodes", made, n - 1);
-  t.root = cur[0];
-  // counts
+  // counts below the clusters that are left (a forest), then the levels above them top-down
   t.objects.assign(2 * (size_t)n - 1, 0);
   t.records.assign(2 * (size_t)n - 1, 0);
   for (uint32_t i = 0; i < n; ++i) t.objects[i] = 1;
@@ -67,13 +66,31 @@ bool build(const std::vector<Box> &leaves, int radius, uint32_t maxRounds, Tree 
   for (uint32_t i = 0; i < n; ++i)
     countUp(i, n, 4, t.child0.data(), t.child1.data(), t.parent.data(), t.objects.data(), t.records.data(),
             [&](uint32_t k) { return arrived[k]++ == 1u; });
+  {
+    std::vector<uint32_t> ids(cur.begin(), cur.begin() + count), obj(count), rec(count);
+    std::vector<Box> bx(count);
+    for (uint32_t k = 0; k < count; ++k) { bx[k] = t.box[ids[k]]; obj[k] = t.objects[ids[k]]; rec[k] = t.records[ids[k]]; }
+    const TopTree top = buildTopTree(ids, bx, obj, rec, n + made, 4);
+    if (top.child0.size() != count - 1) return fail("top tree size", (long)top.child0.size(), count - 1);
+    for (uint32_t k = 0; k + 1 < count; ++k) {
+      const uint32_t id = n + made + k;
+      if (id > 2 * n - 2) return fail("top node id", id);
+      t.child0[id - n] = top.child0[k]; t.child1[id - n] = top.child1[k];
+      t.box[id] = top.box[k]; t.objects[id] = top.objects[k]; t.records[id] = top.records[k]; t.parent[id] = top.parent[k];
+    }
+    for (uint32_t k = 0; k < count; ++k)
+      if (count > 1) t.parent[ids[k]] = top.parentOfItem[k];
+    made += count - 1;
+    if (made != n - 1) return fail("number of internal nodes", made, n - 1);
+    t.root = top.root;
+  }
   if (t.objects[t.root] != n) return fail("objects under the root", t.objects[t.root], n);
   return true;
 }
 
-bool check(const std::vector<Box> &leaves, int radius, uint32_t maxRounds, const char *name) {
+bool check(const std::vector<Box> &leaves, int radius, uint32_t maxRounds, const char *name, uint32_t topTarget = 1) {
   Tree t;
-  if (!build(leaves, radius, maxRounds, t)) { std::printf("  in case %s\n", name); return false; }
+  if (!build(leaves, radius, maxRounds, topTarget, t)) { std::printf("  in case %s\n", name); return false; }
   const uint32_t n = t.n;
   // every object gets its own place in the depth-first order; every record its own index below records[root]
   std::vector<char> seen(n, 0), recSeen(std::max<uint32_t>(1, t.records[t.root]), 0);
@@ -151,6 +168,27 @@ int main() {
       }
       ok &= check(bad, radius, 3000, "NaN and infinite boxes");
     }
+  }
+  // clustering stopped early, the levels above the remaining clusters built top-down (what the GPU build does)
+  std::printf("with a top-down top\n");
+  for (uint32_t top : {2u, 7u, 64u, 2048u, 100000u}) {
+    std::vector<Box> soup;
+    for (int i = 0; i < 20000; ++i) soup.push_back(boxAt(U(rng) * 10, U(rng) * 10, U(rng) * 10, U(rng) * 0.1f));
+    std::sort(soup.begin(), soup.end(), [](const Box &a, const Box &b) { return a.mn[0] < b.mn[0]; });
+    ok &= check(soup, 16, 400, "random soup", top);
+    std::vector<Box> same(3000, boxAt(1, 2, 3, 0.5f));
+    ok &= check(same, 16, 40, "3000 identical boxes", top);
+    std::vector<Box> bad;
+    const float nan = std::nanf("");
+    for (int i = 0; i < 3000; ++i) {
+      Box b = boxAt(U(rng), U(rng), U(rng), 0.01f);
+      if (i % 7 == 0) b = Box{{nan, nan, nan}, {nan, nan, nan}};
+      if (i % 11 == 0) b.mx[1] = INFINITY;
+      bad.push_back(b);
+    }
+    ok &= check(bad, 16, 3000, "NaN and infinite boxes", top);
+    ok &= check({boxAt(0, 0, 0, 1)}, 16, 8, "one object", top);
+    ok &= check({boxAt(0, 0, 0, 1), boxAt(2, 0, 0, 1), boxAt(4, 0, 0, 1)}, 16, 8, "three objects", top);
   }
   std::printf(ok ? "ok\n" : "FAILED\n");
   return ok ? 0 : 1;

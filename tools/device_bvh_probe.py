@@ -38,10 +38,10 @@ ids0, t0 = host.trace_primary()
 st = frame_ms(host, o)
 print(f"host SAH tree:        frame {st.msTotal:8.2f} ms (extend {st.msExtend:.2f}, shadow {st.msShadow:.2f}) {st.note}", flush=True)
 raw = capi.HostScene.load(d + "/readme.sdml").flatten_without_bvh()
-for kind in ("ploc:16", "ploc:64", "lbvh"):
+for kind in os.environ.get("PROBE_TREES", "ploc:2048,ploc:1,lbvh").split(","):
     os.environ["RT_DEVICE_BVH"] = kind.split(":")[0]
     if ":" in kind:
-        os.environ["RT_PLOC_RADIUS"] = kind.split(":")[1]
+        os.environ["RT_PLOC_TOP"] = kind.split(":")[1]  # clusters left when the clustering hands over to the top-down top (1 = clustering to the root)
     dev = capi.device_scene(raw.desc)
     ids1, t1 = dev.trace_primary()
     same = bool(np.array_equal(t0.view(np.uint32), t1.view(np.uint32)))
