@@ -20,6 +20,7 @@ o = hs.desc.contents.options
 spp = int(os.environ.get("PROBE_SPP", "256"))
 opt = capi.RtOptions(o.width, o.height, o.bias, o.exposure, o.maxBounces, spp, o.fisheye, o.focus, o.lens)
 parts = int(os.environ.get("PROBE_PARTS", "2"))
+share = int(os.environ.get("PROBE_SHARE", "1"))  # the work is 1/share of the frame (one rank's tiles of `share` GPUs), split in `parts`
 one = capi.device_scene(hs.desc)
 one.set_view(options=opt)
 many = [capi.device_scene(hs.desc) for _ in range(parts)]
@@ -36,15 +37,15 @@ def timed(fn, reps=3):
 
 
 def together():
-    th = [threading.Thread(target=lambda k=k: many[k].render(download=False, part_index=k, part_count=parts)) for k in range(parts)]
+    th = [threading.Thread(target=lambda k=k: many[k].render(download=False, part_index=k * share, part_count=parts * share)) for k in range(parts)]
     for t in th: t.start()
     for t in th: t.join()
 
 
 def in_turn():
     for k in range(parts):
-        many[k].render(download=False, part_index=k, part_count=parts)
+        many[k].render(download=False, part_index=k * share, part_count=parts * share)
 
 
-print(f"{spp} spp: one scene {timed(lambda: one.render(download=False)):.1f} ms; {parts} partitions in turn {timed(in_turn):.1f} ms; "
+print(f"{spp} spp, 1/{share} of the frame: one scene {timed(lambda: one.render(download=False, part_index=0, part_count=share)):.1f} ms; {parts} partitions in turn {timed(in_turn):.1f} ms; "
       f"{parts} partitions at the same time {timed(together):.1f} ms")
