@@ -163,6 +163,9 @@ constexpr int kTicketStride = 32;  // dwords between the ticket counters of neig
 constexpr uint32_t kTicketChunkMax = RT_CHUNK_MAX, kTicketChunkMin = 64, kChunksPerWave = RT_CHUNK_DIV;
 
 enum { TRAV_CLOSEST = 0, TRAV_ANY = 1, TRAV_POINT_LIGHT = 2, TRAV_SKIP = 3 };
+// Added to TRAV_POINT_LIGHT while a query travels through the engine: its answer does not depend on the order in which
+// its subtrees are visited (see "SPLIT" in traverseQueue). A TRAV_ANY query never depends on it.
+constexpr int TRAV_ORDER_FREE = 4;
 
 // Scheduling thresholds of the traversal engine (lanes of one 64-lane wavefront).
 #ifndef RT_POOL_SLOTS
@@ -215,6 +218,26 @@ constexpr int kMaxTreeDepth = kMaxStack;
 // visited in exactly the reference's order. The grid is sized to fill the GPU once (persistent wavefronts); a wavefront
 // ends when the queue is exhausted, its pool is empty and its own lanes are done, so nothing ever waits on another wavefront.
 //
+// SPLIT. The last wavefronts of a launch run with most lanes idle, and a launch is over only when its longest query is: on
+// the bench scene a few visibility queries per frame take 1 500 - 5 700 steps (paths that wandered 1e7 units out along an
+// infinite plane: from there every box of the scene passes the slab test by a coin flip of rounding), a hundred times the
+// average, at one memory round trip per step. Once the queue is exhausted and the pool empty, every lane that is still
+// working on a visibility query whose answer cannot depend on the order of the visits hands the top entry of its stack to
+// an idle lane, as a prepared query that starts at that subtree; the helpers do the same at the next vote, so the lanes
+// at work double per vote. Only for sources whose store() ignores "not occluded" (Source::kVisibilitySplit): every part
+// reports on its own, and the query is occluded if any part says so.
+//   TRAV_ANY: the first object the loop accepts ends the query and until then the closest t is infinite, so no box is ever
+//     culled by it: the query is occluded iff some object, reachable through boxes that pass the slab test, is hit.
+//   TRAV_POINT_LIGHT, under the conditions checked at prepare time (TRAV_ORDER_FREE): the predicate |o - hit| < bulbDist
+//     holds for every t <= bulbDist / 2 (|o|_1 <= 2^14 bulbDist bounds the rounding of the hit point), so a hit the loop
+//     accepts without ending there has t > bulbDist / 2, and so has the closest t as long as the query runs. Every box of
+//     the tree lies inside the root box and the slab test is monotone in the box's coordinates (finite boxes, finite ray),
+//     so no box is entered at a parameter beyond the root box's exit parameter, which is below bulbDist / 4: the
+//     culling comparison `entry < closest t` (src/acceleration/BVH.cpp:302-305, parameter against distance as in the
+//     reference) is true whenever it is made, in any order, and an occluder (t below the threshold of the predicate, hence
+//     below the closest t) is accepted whenever it is tested. The query is in shadow iff some reachable object has such a t.
+// Counting launches (COUNT) do not split, so that their step counts stay those of the reference's loop.
+//
 // Query kinds:
 //   TRAV_CLOSEST      Scene::findClosestObject (src/scene/raytracer.cpp:187-196)
 //   TRAV_ANY          the boolean of Scene::findAnyObject (:174-185): stops at the first object the closest-hit loop
@@ -231,6 +254,8 @@ constexpr int kMaxTreeDepth = kMaxStack;
 //   uint32_t fetch(uint32_t idx, V3 &o, V3 &d, int &mode, float &bulbDist) load query idx, return a tag for store()
 //   void store(uint32_t tag, HitRec hit, bool occluded, V3 o, V3 nd)       deliver its result
 //   static constexpr bool kPlanesDone                                      the planes were tested before the query was queued
+//   static constexpr bool kVisibilitySplit                                 store() of a visibility query does nothing unless `occluded`, and may
+//                                                                          be called several times for one tag (see "SPLIT" below)
 //   static constexpr bool kFiltered                                        the queue is sparse and the source can tell cheaply where its
 //                                                                          queries are; it then also has
 //   int classify(uint32_t idx)                                             0 = nothing there, 1 = a query to fetch, other = see passedOver
@@ -306,6 +331,7 @@ template <class Source, bool RUNTIME_MODE, bool COUNT, int K, int BLOCK>
 RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint2 *ldsStack, uint32_t *ldsPool, TravCounters &tc) {
   static_assert((K & (K - 1)) == 0, "K must be a power of two");
   static_assert((kPoolSlots & (kPoolSlots - 1)) == 0 && kPoolSlots <= 64, "pool size");
+  constexpr bool kSplit = RUNTIME_MODE && Source::kVisibilitySplit && !COUNT;
   const uint32_t total = src.total();
   const uint32_t laneId = __lane_id();
   const char *nodeBase = reinterpret_cast<const char *>(S.nodes);
@@ -373,7 +399,7 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
     bool occluded = early;
     if (!early) {
       if (plane >= 0 && tP < tB) { tB = tP; pB = S.numPrims + plane; }
-      if (!(RUNTIME_MODE && qmode == TRAV_POINT_LIGHT)) occluded = pB >= 0;
+      if (!(RUNTIME_MODE && (qmode & 3) == TRAV_POINT_LIGHT)) occluded = pB >= 0;
     }
     HitRec h;
     h.t = pB >= 0 ? tB : kInf;
@@ -508,8 +534,13 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
                   qcut = __uint_as_float(bits);
                 }
               }
-              float rootDist = intersectAABB(qo, qinv, S.rootMin[0], S.rootMin[1], S.rootMin[2], S.rootMax[0], S.rootMax[1], S.rootMax[2]);
+              float rootIn, rootOut;  // intersectAABB (src/acceleration/BVH.cpp:390-409), keeping the exit parameter
+              slabExact(qo, qinv, S.rootMin[0], S.rootMin[1], S.rootMin[2], S.rootMax[0], S.rootMax[1], S.rootMax[2], rootIn, rootOut);
+              const float rootDist = (rootOut >= rootIn && rootOut > 0) ? rootIn : kInf;
               if (rootDist < qcut) qfirst = S.rootRef;
+              if (kSplit && qmode == TRAV_POINT_LIGHT && qfinite && qbulb < 1e30f && rootOut < 0.25f * qbulb &&
+                  fabsf(qo.x) + fabsf(qo.y) + fabsf(qo.z) <= 16384.0f * qbulb)
+                qmode |= TRAV_ORDER_FREE;  // see "SPLIT" above
             }
             if (qfirst == kNoBvh) deliver(qitem, false, qmode, kInf, -1, qtPlane, qplane, qo, qnd);  // nothing to traverse
             else pooled = true;
@@ -532,6 +563,28 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
         q[12 * kPoolSlots] = (RUNTIME_MODE ? (__float_as_uint(qcut) >> 16) : (uint32_t)(qplane + 1)) | ((uint32_t)qmode << 16) | ((uint32_t)qfinite << 20);
       }
       poolCount += (uint32_t)__popcll(mPooled);
+    }
+    // ------------------------------------------------------------------ SPLIT: the end of a launch, lanes are idle
+    if (kSplit && service && exhausted && poolCount == 0) {
+      const bool gives = (op == OP_INNER || op == OP_PRIM) && (mode == TRAV_ANY || (mode & TRAV_ORDER_FREE) != 0) && sp > lo;
+      const unsigned long long mGives = __ballot(gives), mIdle = __ballot(op == OP_IDLE);
+      if (mGives != 0ull && mIdle != 0ull) {
+        const uint32_t nGive = min((uint32_t)__popcll(mGives), min((uint32_t)__popcll(mIdle), (uint32_t)kPoolSlots));
+        const uint32_t rank = (uint32_t)__popcll(mGives & ((1ull << laneId) - 1ull));
+        if (gives && rank < nGive) {
+          --sp;  // sp > lo: the top entry is in LDS; every entry of such a query is still wanted (nothing culls by the closest t)
+          const uint2 e = stackCol[(sp & (K - 1)) * BLOCK];
+          uint32_t *q = pool + ((poolHead + rank) & (kPoolSlots - 1));
+          q[0 * kPoolSlots] = __float_as_uint(o.x); q[1 * kPoolSlots] = __float_as_uint(o.y); q[2 * kPoolSlots] = __float_as_uint(o.z);
+          q[3 * kPoolSlots] = __float_as_uint(nd.x); q[4 * kPoolSlots] = __float_as_uint(nd.y); q[5 * kPoolSlots] = __float_as_uint(nd.z);
+          q[6 * kPoolSlots] = __float_as_uint(inv.x); q[7 * kPoolSlots] = __float_as_uint(inv.y); q[8 * kPoolSlots] = __float_as_uint(inv.z);
+          q[9 * kPoolSlots] = __float_as_uint(bulbDist);
+          q[10 * kPoolSlots] = item;
+          q[11 * kPoolSlots] = e.y;
+          q[12 * kPoolSlots] = (__float_as_uint(cutLimit) >> 16) | ((uint32_t)mode << 16) | ((uint32_t)finite << 20);
+        }
+        poolCount = nGive;
+      }
     }
     // ------------------------------------------------------------------ idle lanes TAKE prepared queries
     if (service) {

@@ -208,6 +208,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DevScene S, PathBuf B, const 
 // ---------------------------------------------------------------------------------------------------- k_extend
 struct ExtendSource {
   static constexpr bool kPlanesDone = false;
+  static constexpr bool kVisibilitySplit = false;
   static constexpr bool kFiltered = false;
   const PathBuf &B;
   const uint32_t *queue;
@@ -448,6 +449,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE
 // The reference traces the zero-contribution queries too; they are reported apart.
 struct ShadowSource {
   static constexpr bool kPlanesDone = true;  // k_shade has tested them
+  static constexpr bool kVisibilitySplit = true;  // store() acts on `occluded` only, and writing the same zero twice is harmless
   static constexpr bool kFiltered = true;    // and has left a code for every (queue position, light)
   const DevScene &S;
   const PathBuf &B;
@@ -741,6 +743,7 @@ RT_DEV int32_t reportedId(const DevScene &S, int32_t prim) {
 
 struct PrimarySource {
   static constexpr bool kPlanesDone = false;
+  static constexpr bool kVisibilitySplit = false;
   static constexpr bool kFiltered = false;
   const DevScene &S;
   int32_t x0, y0, w, h;
@@ -784,6 +787,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_primary(DevScene S, int32_t x0
 template <bool ANY>
 struct RaysSource {
   static constexpr bool kPlanesDone = false;
+  static constexpr bool kVisibilitySplit = false;
   static constexpr bool kFiltered = false;
   const DevScene &S;
   int64_t n;

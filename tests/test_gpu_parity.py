@@ -674,6 +674,45 @@ def test_point_light_behind_flat_boxes():
         assert st.raysClosest + st.raysAny + st.raysSkipped == ost.raysClosest + ost.raysAny
 
 
+def test_visibility_queries_from_far_away_split_or_not_same_frame():
+    """Behind a cluster of spheres lies a plane ten million units away. Every path that reaches it asks for the bulb from
+    there: a ray whose origin has an ulp of one unit, for which the slab test of every box near the bulb is a coin flip, so
+    the query wanders through much of the tree (the bench scene has a dozen of these per frame, from paths that strayed
+    along its infinite planes, and they used to be the tail of every launch). At the end of a launch the library hands
+    parts of such queries to idle lanes; a counting launch does not. Both must give the frame of the reference's loop."""
+    hs = capi.HostScene.new(128, 96)
+    mats = [0, hs.add_material(capi.RT_MAT_PLASTIC, Kd=0.7, Kr=0.3, eta=1.5, roughness=0.2)]
+    rng = np.random.default_rng(11)
+    for k in range(1500):
+        hs.add_sphere(tuple(rng.normal(size=3) * np.array([1.5, 1.0, 1.0]) + np.array([0, 0, -5])), float(rng.uniform(0.03, 0.12)),
+                      color=tuple(rng.uniform(0.2, 1, size=3)) + (1.0,), material=mats[k % 2])
+    hs.add_plane((0, 0, 1), 1.0e7, color=(0.8, 0.8, 0.7, 1.0))
+    hs.add_light(capi.RT_LIGHT_POINT, color=(5e13, 5e13, 4e13, 1.0), v=(0.5, 1.0, -4.0))  # bright enough to matter at 1e7 units
+    hs.add_light(capi.RT_LIGHT_DISTANT, color=(0.4, 0.4, 0.5, 1.0), v=(-1, 1, 0.5))
+    hs.add_light(capi.RT_LIGHT_ENVIRONMENT, color=(0.2, 0.2, 0.2, 1.0), radius=10.0)
+    hs.set_camera(eye=(0, 0, 0), forward=(0, 0, -1), up=(0, 1, 0))
+    hs.set_options(128, 96, maxBounces=3, numRays=4)
+    hs = hs.build()
+    dev, orc = capi.device_scene(hs.desc), oracle_scene(hs.desc)
+    try:
+        img, st = dev.render(seed=7)
+        counted, stc = dev.render(seed=7, collect_counters=True)
+        ref, ost = orc.render(seed=7)
+        assert np.array_equal(img.view(np.uint32), counted.view(np.uint32)), "split and unsplit visibility queries disagree"
+        assert np.array_equal(img[..., 3], ref[..., 3])
+        far = ref[..., :3].max(-1) > 0
+        assert far.mean() > 0.25  # the plane is lit from ten million units away, where it is not in the cluster's shadow
+        off = int((np.abs(img[..., :3] - ref[..., :3]).max(-1) > 1e-3 * np.maximum(1.0, ref[..., :3].max(-1))).sum())
+        assert off <= 2, f"{off} pixels differ"
+        # the far queries are the long ones: they lift the average over ALL visibility queries, most of which a plane answers
+        # or the root box turns away, to a multiple of what a path-extension ray of the cluster takes
+        assert ost.innerShadow / ost.raysShadow > 2 * ost.innerExtend / ost.raysExtend
+        assert 0 < stc.innerShadow <= ost.innerShadow
+        assert st.raysClosest + st.raysAny + st.raysSkipped == ost.raysClosest + ost.raysAny
+    finally:
+        dev.close()
+
+
 def test_hip_library_rejects_what_it_cannot_do(scenes):
     _, dev, _ = scenes("config1")
     with pytest.raises(RuntimeError, match="RT_RNG_COUNTER"):
