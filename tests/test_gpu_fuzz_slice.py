@@ -4,7 +4,8 @@ bits of t, points, normals, visibility answers) and one tiny frame (alpha exact,
 than 1e-3: a single path may branch the other way on a last-bit difference of the device's sinf / cosf). One scene in
 five comes from the family that once got through every hand-written test: meshes on a coarse grid with flat,
 axis-aligned boxes around point lights closer than one unit (visibility rays with |d| < 1 that run almost parallel to the
-boxes). The second test pins the min/max form of the slab test against the compare-and-select form of
+boxes). Another one in five puts a cluster of objects and a bright bulb in front of a plane up to 2e8 units away: the
+visibility queries from there are the ones the library splits over idle lanes at the end of a launch. The second test pins the min/max form of the slab test against the compare-and-select form of
 src/acceleration/BVH.cpp:390-409 on the same rays."""
 import os
 import time
@@ -27,26 +28,26 @@ WALL_BUDGET_S = 90.0  # a guard, not the plan: the slice takes about 25 s on the
 def test_random_scenes_match_the_oracle(seed, count):
     rng = np.random.default_rng(seed)
     t0 = time.time()
-    bad, diverged, rays, flat_scenes, near_bulbs = [], 0, 0, 0, 0
+    bad, diverged, rays, flat_scenes, far_scenes = [], 0, 0, 0, 0
     for k in range(count):
-        flat = k % 5 == 4
-        hs = fuzz_parity.flat_box_scene(rng, k) if flat else fuzz_parity.random_scene(rng, k)
-        o, d = (fuzz_parity.near_parallel_rays if flat else fuzz_parity.random_rays)(rng, RAYS_PER_SCENE)
+        hs, rays_of, family = fuzz_parity.scene_of_the_stream(rng, k)
+        o, d = rays_of(rng, RAYS_PER_SCENE)
         dev, orc = capi.device_scene(hs.desc), oracle_scene(hs.desc, threads=8)
         try:
             res = fuzz_parity.check_scene(hs, dev, orc, o, d, k)
         finally:
             dev.close(); orc.close()
-        flat_scenes += int(flat)
+        flat_scenes += int(family == "flat")
+        far_scenes += int(family == "far")
         rays += res["rays"]
         diverged += int(res["ok"] and not res["same_counts"])
         if not res["ok"]:
             bad.append(f"seed {seed} scene {k}: {res['what']}")
         assert time.time() - t0 < WALL_BUDGET_S, f"slice overran its budget after {k + 1} scenes"
-    print(f"seed {seed}: {count} scenes ({flat_scenes} of the flat-box family), {rays / 1e6:.1f} M rays, {diverged} frames with a diverged "
+    print(f"seed {seed}: {count} scenes ({flat_scenes} of the flat-box family, {far_scenes} of the far-plane family), {rays / 1e6:.1f} M rays, {diverged} frames with a diverged "
           f"path, {time.time() - t0:.1f} s")
     assert not bad, "\n".join(bad[:10])
-    assert flat_scenes >= count // 5 - 1
+    assert flat_scenes >= count // 5 - 1 and far_scenes >= count // 5 - 1
     # single diverged paths are expected in a few percent of the frames, not in most
     assert diverged <= count // 8
 

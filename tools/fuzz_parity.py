@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """GPU box: randomised parity. Random scenes (triangle soups with degenerate and huge triangles, spheres, planes, point /
-distant / environment lights, random materials), random cameras, and rays with extreme directions (zero components,
-tiny and huge lengths, origins inside boxes and far away): closest and any-hit queries must equal the CPU restatement
-bit for bit; rendered frames must have the same alpha and at most 1 % of their pixels off by more than 1e-3.
+distant / environment lights, random materials; meshes on coarse grids around near bulbs; clusters in front of a plane
+millions of units away), random cameras, and rays with extreme directions (zero components, tiny and huge lengths,
+origins inside boxes and far away): closest and any-hit queries must equal the CPU restatement bit for bit; rendered
+frames must have the same alpha and at most 1 % of their pixels off by more than 1e-3.
 
     python tools/fuzz_parity.py [--seconds 120] [--seed 1]"""
 import argparse
@@ -126,6 +127,57 @@ def flat_box_scene(rng, k):
     hs.set_camera(eye=tuple(rng.normal(size=3) * 0.3), forward=tuple(rng.normal(size=3) * 0.2 + np.array([0, 0, -1])), up=(0, 1, 0))
     hs.set_options(w, h, maxBounces=int(rng.integers(1, 5)), numRays=int(rng.integers(1, 4)))
     return hs.build()
+
+
+def far_plane_scene(rng, k):
+    """A cluster of spheres and triangles, a point light beside it, and a plane 1e4 .. 2e8 units behind it. Every path that
+    reaches the plane asks for the bulb from there: the origin's ulp is up to several units, so the slab test of every box
+    near the bulb is decided by rounding and the query wanders through much of the tree, over a distance (the bulb's)
+    that dwarfs the root box. Those are the queries the library splits over idle lanes at the end of a launch; their
+    answers must still be the reference loop's. The bulb is bright enough to light the plane from that far; distant lights
+    add any-hit queries from the same points."""
+    w, h = int(rng.integers(12, 65)), int(rng.integers(12, 65))
+    hs = capi.HostScene.new(w, h)
+    mats = [hs.add_material(capi.RT_MAT_DEFAULT),
+            hs.add_material(capi.RT_MAT_PLASTIC, Kd=0.7, Kr=0.3, eta=1.5, roughness=0.2),
+            hs.add_material(capi.RT_MAT_MIRROR, Kr=0.9, eta=1.5)]
+    center = np.array([0.0, 0.0, -4.0])
+    ntri = int(rng.choice([0, 60, 800, 3000]))
+    if ntri:
+        nv = max(3, ntri // 2)
+        hs.add_mesh(rng.normal(size=(nv, 3)) * 0.6, rng.normal(size=(nv, 3)), rng.integers(0, nv, size=(ntri, 3)), center=tuple(center),
+                    scale=float(rng.uniform(0.5, 2)), color=tuple(rng.uniform(0.2, 1, size=3)) + (1.0,), material=int(rng.choice(mats)))
+    for _ in range(int(rng.choice([3, 30, 300]))):
+        hs.add_sphere(tuple(rng.normal(size=3) * np.array([1.5, 1.0, 1.0]) + center), float(rng.uniform(0.03, 0.3)),
+                      color=tuple(rng.uniform(0, 1, size=3)) + (1.0,), material=int(rng.choice(mats)))
+    dist = float(10.0 ** rng.uniform(4, 8.3))
+    n = np.array([0.0, 0.0, 1.0]) + rng.normal(size=3) * float(rng.choice([0.0, 0.05, 0.3]))
+    n /= np.linalg.norm(n)
+    hs.add_plane(tuple(n), dist, color=tuple(rng.uniform(0.3, 1, size=3)) + (1.0,), material=int(rng.choice(mats[:2])))
+    if rng.random() < 0.3:  # a floor under the cluster as well
+        hs.add_plane((0.0, 1.0, 0.0), float(rng.uniform(1.5, 4)), color=tuple(rng.uniform(0, 1, size=3)) + (1.0,), material=mats[0])
+    for _ in range(int(rng.integers(1, 3))):
+        hs.add_light(capi.RT_LIGHT_POINT, color=tuple(rng.uniform(0.05, 0.6, size=3) * dist * dist) + (1.0,),
+                     v=tuple(rng.normal(size=3) * np.array([1.5, 1.5, 1.0]) + center + np.array([0, 0, 1.0])))
+    if rng.random() < 0.5:
+        hs.add_light(capi.RT_LIGHT_DISTANT, color=tuple(rng.uniform(0, 1, size=3)) + (1.0,), v=tuple(rng.normal(size=3) + np.array([0, 0, 1.0])))
+    hs.set_camera(eye=tuple(rng.normal(size=3) * 0.3), forward=tuple(rng.normal(size=3) * 0.15 + np.array([0, 0, -1])), up=(0, 1, 0))
+    # Direct light only, and no environment light: a direction drawn with sinf / cosf differs in its last bit between the
+    # device's and glibc's functions, and from millions of units away a last bit is a different hit back at the cluster;
+    # with a bulb this bright one such path turns a pixel from black to white. Without drawn directions no transcendental
+    # function is involved and the frames are expected to agree everywhere.
+    hs.set_options(w, h, maxBounces=1, numRays=int(rng.integers(1, 4)))
+    return hs.build()
+
+
+def scene_of_the_stream(rng, k):
+    """Scene k of a campaign and the rays traced through it: three in five are random soups, one in five comes from the
+    flat-box family, one in five from the far-plane family."""
+    if k % 5 == 4:
+        return flat_box_scene(rng, k), near_parallel_rays, "flat"
+    if k % 5 == 2:
+        return far_plane_scene(rng, k), random_rays, "far"
+    return random_scene(rng, k), random_rays, "soup"
 
 
 def near_parallel_rays(rng, n, cell=0.25):
@@ -276,9 +328,8 @@ def main():
     t0 = time.time()
     k = bad = rays = diverged = 0
     while time.time() - t0 < args.seconds:
-        flat = k % 5 == 4
-        hs = flat_box_scene(rng, k) if flat else random_scene(rng, k)
-        o, d = near_parallel_rays(rng, 20000) if flat else random_rays(rng, 20000)
+        hs, rays_of, _ = scene_of_the_stream(rng, k)
+        o, d = rays_of(rng, 20000)
         if args.only >= 0 and k < args.only:
             k += 1
             continue
