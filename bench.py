@@ -302,7 +302,7 @@ def main():
                          if prof else None),
         # The hardware rate the kernel comes nearest to. It does NOT bind: fetching records by quads (3.8 accesses per clock)
         # gains 0-9 % at equal occupancy, while time follows the number of resident waves and every extra dependent round
-        # trip per node step (experiment tables in DESIGN.md).
+        # trip per node step (7 / 6 / 5 / 4 waves per SIMD: 50.6 / 57.9 / 65.9 / 79.3 ms; one more dependent read per step: + 17.5 %).
         "nearest_roof": {"name": "L1 scattered-access rate", "achieved": l1, "peak": L1_PEAK,
                          "unit": "L1 accesses per clock per CU (TCP_TOTAL_CACHE_ACCESSES_sum / 256 CUs / GPU cycles)",
                          "frac": round(l1 / L1_PEAK, 4) if l1 else None, "binds": False,
