@@ -549,3 +549,34 @@ def test_redchair_tree_is_buildable_and_consistent(golden):
     a, b = orc.trace_closest(o, d), brute.trace_closest(o, d)
     assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and (a[0] >= 0).sum() > 400
     orc.close(); brute.close()
+
+
+def test_scene_stream_of_the_randomised_campaign_builds_and_renders_on_the_cpu():
+    """The generator behind tools/fuzz_parity.py and the GPU suite's fixed slice, without a GPU: every family of the
+    stream builds on the host, and the CPU restatement renders it to a finite frame. The far-plane family must really put
+    lit geometry millions of units away (that is what makes its visibility queries wander through the tree), with direct
+    light only."""
+    from tools import fuzz_parity
+    rng = np.random.default_rng(5)
+    seen = {}
+    for k in range(15):
+        hs, rays_of, family = fuzz_parity.scene_of_the_stream(rng, k)
+        o, d = rays_of(rng, 500)
+        assert o.shape == d.shape == (500, 3) and o.dtype == d.dtype == np.float32
+        seen[family] = seen.get(family, 0) + 1
+        orc = oracle_scene(hs.desc, threads=4)
+        try:
+            ref, st = orc.render(seed=k)
+            ids, t, pt, nm = orc.trace_closest(o, d)
+        finally:
+            orc.close()
+        dsc = hs.desc.contents
+        assert ref.shape == (dsc.options.height, dsc.options.width, 4)
+        assert np.isfinite(ref).all(), f"scene {k} ({family})"
+        if family == "far":
+            assert dsc.options.maxBounces == 1 and dsc.numPlanes >= 1
+            far = max(abs(float(v)) for v in dsc.planes[0].point)
+            assert far > 5e3
+            assert all(dsc.lights[i].type != capi.RT_LIGHT_ENVIRONMENT for i in range(dsc.numLights))
+            assert (ref[..., :3].max(-1) > 0).mean() > 0.02  # the bulb reaches the plane
+    assert seen == {"soup": 9, "far": 3, "flat": 3}
