@@ -229,8 +229,12 @@ constexpr int kMaxTreeDepth = kMaxStack;
 //   TRAV_ANY: the first object the loop accepts ends the query and until then the closest t is infinite, so no box is ever
 //     culled by it: the query is occluded iff some object, reachable through boxes that pass the slab test, is hit.
 //   TRAV_POINT_LIGHT, under the conditions checked at prepare time (TRAV_ORDER_FREE): the predicate |o - hit| < bulbDist
-//     holds for every t <= bulbDist / 2 (|o|_1 <= 2^14 bulbDist bounds the rounding of the hit point), so a hit the loop
-//     accepts without ending there has t > bulbDist / 2, and so has the closest t as long as the query runs. Every box of
+//     holds for every 0 <= t <= bulbDist / 2 (|o|_1 <= 2^14 bulbDist bounds the rounding of the hit point, bulbDist < 1e12
+//     keeps its squares finite), so a hit the loop accepts without ending there has t > bulbDist / 2, and so has the
+//     closest t as long as the query runs. (No accepted t is below zero by more than rounding: a triangle rejects t < 0,
+//     and a sphere's t = tcen - tOffset with tcen >= tOffset up to the rounding of |centre - o| and the radius, which the
+//     scene's extent bounds: S.cutEps, 2^-20 of the extent at least, must not exceed bulbDist / 64, and the root box
+//     lies within bulbDist / 4 of the origin. S.cutEps is zero for scenes with unbounded objects: no split there.) Every box of
 //     the tree lies inside the root box and the slab test is monotone in the box's coordinates (finite boxes, finite ray),
 //     so no box is entered at a parameter beyond the root box's exit parameter, which is below bulbDist / 4: the
 //     culling comparison `entry < closest t` (src/acceleration/BVH.cpp:302-305, parameter against distance as in the
@@ -538,8 +542,8 @@ RT_DEV void traverseQueue(const DevScene &S, Source &src, uint32_t *ticket, uint
               slabExact(qo, qinv, S.rootMin[0], S.rootMin[1], S.rootMin[2], S.rootMax[0], S.rootMax[1], S.rootMax[2], rootIn, rootOut);
               const float rootDist = (rootOut >= rootIn && rootOut > 0) ? rootIn : kInf;
               if (rootDist < qcut) qfirst = S.rootRef;
-              if (kSplit && qmode == TRAV_POINT_LIGHT && qfinite && qbulb < 1e30f && rootOut < 0.25f * qbulb &&
-                  fabsf(qo.x) + fabsf(qo.y) + fabsf(qo.z) <= 16384.0f * qbulb)
+              if (kSplit && qmode == TRAV_POINT_LIGHT && qfinite && qbulb < 1e12f && rootOut < 0.25f * qbulb &&
+                  fabsf(qo.x) + fabsf(qo.y) + fabsf(qo.z) <= 16384.0f * qbulb && S.cutEps > 0.0f && S.cutEps <= 0.015625f * qbulb)
                 qmode |= TRAV_ORDER_FREE;  // see "SPLIT" above
             }
             if (qfirst == kNoBvh) deliver(qitem, false, qmode, kInf, -1, qtPlane, qplane, qo, qnd);  // nothing to traverse
